@@ -1,0 +1,129 @@
+/* mpr_hip.h -- C ABI of libmpr_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * train_multi hot path of imveikka/multimodal_plankton_recognition.
+ *
+ * The reference has no FFI: its hot path bottoms out in torch / timm / cuDNN calls.  Each entry
+ * point below names the reference call it stands in for (paths relative to the reference root).
+ * Conventions:
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the library never allocates,
+ *     frees or synchronises -- the caller (PyTorch's caching allocator in this repo) owns all memory;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing else;
+ *   - activations are channels-last bf16 ([B,H,W,C]; a 1-D sequence is H == 1), statistics,
+ *     embeddings, losses and parameters / gradients are fp32 (parameters in torch's own layouts);
+ *   - return value: 0 = ok, 1 = invalid argument, 2 = HIP runtime error; mpr_last_error() gives the
+ *     message for the calling thread.  Nothing aborts.
+ *   - "stat rows": train-mode BatchNorm statistics are produced as per-workgroup partial sums
+ *     [rows][2][C] (sum, sum of squares) and reduced by mpr_bn_finalize_stats; the *_stat_rows /
+ *     mpr_bn_reduce_rows functions give the number of rows the producer will write.
+ */
+#ifndef MPR_HIP_H
+#define MPR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+int mpr_abi_version(void);
+const char* mpr_target_arch(void);                 /* "gfx950" */
+const char* mpr_last_error(void);
+void mpr_set_error(const char* fmt, ...);
+int mpr_device_check(char* name, int name_len);    /* 0 iff device 0 is gfx950; name: HOST buffer */
+
+/* ---- convolution as implicit GEMM (bf16 MFMA, fp32 accumulate) ------------------------------
+ * Stand in for nn.Conv2d inside timm's ResNet (src/image_encoder.py:24) and nn.Conv1d in
+ * ProfileCNN / _BasicBlock (src/profile_encoder.py:125,128,167,187-190), forward and backward. */
+int mpr_conv_packed_sizes(int K, int C, int R, int S, long long* fwd_elems, long long* dgrad_elems);
+int mpr_conv_pack_weights(const float* w_oihw, void* w_fwd, void* w_dgrad /* may be NULL */, int K, int C, int R,
+                          int S, void* stream);
+int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K);
+int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may be NULL */, int B, int H, int W,
+                 int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
+int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add /* may be NULL */, int B, int H,
+                   int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
+int mpr_conv_wgrad(const void* x, const void* dy, float* workspace /* K*R*S*C floats */, float* dw_oihw,
+                   int accumulate, int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph,
+                   int pw, void* stream);
+
+/* ---- stem convolutions (few input channels, fp32 input, direct) -----------------------------
+ * timm ResNet conv1 (1->64, 7x7/2) and ProfileCNN.conv1 (src/profile_encoder.py:167). */
+int mpr_stem_fwd_stat_rows(int B, int P, int Q, int K);
+int mpr_stem_fwd(const float* x, const float* w_oihw, void* y, float* stats /* may be NULL */, int B, int H, int W,
+                 int Cin, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
+int mpr_stem_wgrad(const float* x, const void* dy, float* dw_oihw, int accumulate, int B, int H, int W, int Cin,
+                   int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
+
+/* ---- BatchNorm, train and eval (nn.BatchNorm1d/2d defaults: src/profile_encoder.py:126,129,168) */
+int mpr_bn_reduce_rows(long long rows, int C);
+int mpr_bn_stats(const void* x, float* partials, long long rows, int C, void* stream);
+int mpr_bn_finalize_stats(const float* partials, int nparts, long long count, const float* gamma, const float* beta,
+                          float* running_mean /* may be NULL */, float* running_var, float momentum, float eps,
+                          float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
+int mpr_bn_eval_coefs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float* scale, float* shift, int C, void* stream);
+int mpr_bn_apply(const void* x, const float* scale, const float* shift, const void* residual /* may be NULL */,
+                 int relu, void* y, long long rows, int C, void* stream);
+/* mask_mode: 0 = dz = dy; 1 = dz = dy * (y > 0); 2 = dz = dy * (x*scale+shift > 0) */
+int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                      const float* scale, const float* shift, int mask_mode, float* partials, long long rows, int C,
+                      void* stream);
+int mpr_bn_bwd_finalize(const float* partials, int nparts, long long count, const float* gamma, const float* mean,
+                        const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef /* [3][C] */,
+                        int C, void* stream);
+int mpr_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coef, const float* scale,
+                     const float* shift, int mask_mode, void* dx, void* dz_out /* may be NULL */, long long rows,
+                     int C, void* stream);
+
+/* ---- pooling (nn.MaxPool1d(3,2,1) src/profile_encoder.py:170, timm maxpool 3x3/2; AdaptiveMaxPool1d(1)
+ *      src/profile_encoder.py:177; timm global average pool) */
+int mpr_bn_relu_maxpool_fwd(const void* x, const float* scale /* NULL: plain max-pool */, const float* shift, void* y,
+                            void* idx /* 1 byte / output element */, int B, int H, int W, int C, int RH, int RW,
+                            int SH, int SW, int PH, int PW, void* stream);
+int mpr_maxpool_bwd(const void* dy, const void* idx, void* dx, int B, int H, int W, int C, int RH, int RW, int SH,
+                    int SW, int PH, int PW, void* stream);
+int mpr_global_avgpool_fwd(const void* x, float* y, int B, int L, int C, void* stream);
+int mpr_global_avgpool_bwd(const float* dy, void* dx, int B, int L, int C, void* stream);
+int mpr_global_maxpool_fwd(const void* x, float* y, int* idx, int B, int L, int C, void* stream);
+int mpr_global_maxpool_bwd(const float* dy, const int* idx, void* dx, int B, int L, int C, void* stream);
+
+/* ---- exact-fp32 batched GEMM: C = alpha*op(A)*op(B) (+bias) + beta*C --------------------------
+ * nn.Linear(bias=False) projections (src/model.py:31-32,40-41,80-82), classifier heads
+ * (src/model.py:164,316), similarity matrix and its gradient products (src/coordination.py:38,89). */
+int mpr_gemm_f32(const float* A, const float* B, float* C, const float* bias /* [N] or NULL */, int M, int N, int K,
+                 int lda, int ldb, int ldc, int transA, int transB, float alpha, float beta, int batch,
+                 long long strideA, long long strideB, long long strideC, void* stream);
+
+/* ---- coordination losses (src/coordination.py:17-112) ----------------------------------------- */
+int mpr_loss_workspace_floats(void);
+int mpr_l2norm_fwd(const float* x, float* u, float* inv_norm, int rows, int D, void* stream);
+int mpr_l2norm_bwd(const float* du, const float* u, const float* inv_norm, const float* x /* may be NULL */,
+                   const float* other, float mse_coef, const float* gout /* [1] or NULL */, float* dx, int rows,
+                   int D, void* stream);
+int mpr_clip_fwd(const float* S, const float* logit_scale, float* row_lse, float* col_lse, float* diag, float* loss,
+                 int buckets, int n, void* stream);
+int mpr_clip_bwd(float* S, const float* logit_scale, const float* row_lse, const float* col_lse, const float* gout,
+                 float* d_logit_scale, float* workspace, int buckets, int n, void* stream);
+int mpr_siglip_fwd(const float* S, const float* logit_scale, const float* bias, float* loss, float* workspace,
+                   int buckets, int n, void* stream);
+int mpr_siglip_bwd(float* S, const float* logit_scale, const float* bias, const float* gout, float* d_logit_scale,
+                   float* d_bias, float* workspace, int buckets, int n, void* stream);
+int mpr_mse_add(const float* a, const float* b, float beta, float* loss, float* workspace, long long total,
+                void* stream);
+
+/* ---- optimiser, encoder tail, classifier loss --------------------------------------------------
+ * optim.SGD over all parameters (src/model.py:147-148); metadata concat + dropout
+ * (src/image_encoder.py:25-29, src/profile_encoder.py:234-240); CrossEntropyLoss + argmax
+ * (src/model.py:167,227). */
+int mpr_sgd_multi(const void* table /* device {float* p; const float* g; float* m; int64 n}[ntensors] */,
+                  int ntensors, long long max_numel, float lr, float momentum, float dampening, float weight_decay,
+                  int nesterov, int first_step, void* stream);
+int mpr_tail_fwd(const float* feat, const long long* meta, float inv_denom, float p_drop, unsigned seed, float* out,
+                 void* mask /* 1 byte / element, needed iff p_drop > 0 */, int B, int F, int Mm, void* stream);
+int mpr_tail_bwd(const float* dout, const void* mask, float p_drop, float* dfeat, int B, int F, int Mm, void* stream);
+int mpr_softmax_ce(const float* logits, const long long* labels /* may be NULL: argmax only */, float* row_loss,
+                   float* loss, long long* argmax, float* dlogits /* may be NULL */, int rows, int C, void* stream);
+int mpr_scale_by_scalar(const float* x, const float* s, float* y, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPR_HIP_H */

@@ -1,0 +1,175 @@
+"""Cross-modal coordination losses -- drop-in counterparts of /root/reference/src/coordination.py
+(same class names, parameters, ``forward(image_emb, profile_emb, buckets=1)`` contract and
+``state_dict`` keys), computed end-to-end in fp32 by the kernels of csrc/loss.hip + gemm_f32.hip.
+"""
+import torch
+from torch import Tensor, nn
+from torch.nn import Parameter
+
+from . import _native as N
+from . import ops
+
+F32 = torch.float32
+
+
+def _prep(image_emb, profile_emb, buckets):
+    assert image_emb.size(0) % buckets == 0, "Batch size must be divisible by number of buckets!"
+    a = image_emb.contiguous().float()
+    p = profile_emb.contiguous().float()
+    n = a.shape[0] // buckets
+    u = torch.empty_like(a)
+    v = torch.empty_like(p)
+    iu = torch.empty(a.shape[0], dtype=F32, device=a.device)
+    iv = torch.empty(a.shape[0], dtype=F32, device=a.device)
+    N.call('mpr_l2norm_fwd', a, u, iu, a.shape[0], a.shape[1])
+    N.call('mpr_l2norm_fwd', p, v, iv, p.shape[0], p.shape[1])
+    D = a.shape[1]
+    S = ops.gemm(u.view(buckets, n, D), v.view(buckets, n, D), trans_b=True)      # [k, n, n] raw cosines
+    return a, p, u, v, iu, iv, S, n
+
+
+def _workspace(device):
+    return torch.empty(N.query('mpr_loss_workspace_floats'), dtype=F32, device=device)
+
+
+def _embedding_grads(ctx, S_grad, gout, a, p, u, v, iu, iv, n, buckets, beta):
+    D = a.shape[1]
+    dU = ops.gemm(S_grad, v.view(buckets, n, D))                       # G V
+    dV = ops.gemm(S_grad, u.view(buckets, n, D), trans_a=True)         # G^T U
+    coef = 2.0 * beta / a.numel() if beta else 0.0
+    da = torch.empty_like(a)
+    dp = torch.empty_like(p)
+    rows = a.shape[0]
+    N.call('mpr_l2norm_bwd', dU, u, iu, a if beta else None, p if beta else None, coef, gout, da, rows, D)
+    N.call('mpr_l2norm_bwd', dV, v, iv, p if beta else None, a if beta else None, coef, gout, dp, rows, D)
+    return da, dp
+
+
+class _ClipFn(torch.autograd.Function):
+    """src/coordination.py:26-47 (+ beta * MSE of :60-64 when beta != 0)."""
+
+    @staticmethod
+    def forward(ctx, image_emb, profile_emb, logit_scale, buckets, beta):
+        a, p, u, v, iu, iv, S, n = _prep(image_emb, profile_emb, buckets)
+        dev = a.device
+        rows = a.shape[0]
+        row_lse = torch.empty(rows, dtype=F32, device=dev)
+        col_lse = torch.empty(rows, dtype=F32, device=dev)
+        diag = torch.empty(rows, dtype=F32, device=dev)
+        loss = torch.empty((), dtype=F32, device=dev)
+        N.call('mpr_clip_fwd', S, logit_scale.detach(), row_lse, col_lse, diag, loss, buckets, n)
+        if beta:
+            N.call('mpr_mse_add', a, p, float(beta), loss, _workspace(dev), a.numel())
+        ctx.save_for_backward(a, p, u, v, iu, iv, S, row_lse, col_lse, logit_scale)
+        ctx.cfg = (n, buckets, beta)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, p, u, v, iu, iv, S, row_lse, col_lse, logit_scale = ctx.saved_tensors
+        n, buckets, beta = ctx.cfg
+        gout = gout.contiguous().float()
+        dls = torch.empty((), dtype=F32, device=a.device)
+        G = S.clone()       # keep the saved logits intact (backward may be re-run)
+        N.call('mpr_clip_bwd', G, logit_scale.detach(), row_lse, col_lse, gout, dls, _workspace(a.device), buckets, n)
+        da, dp = _embedding_grads(ctx, G, gout, a, p, u, v, iu, iv, n, buckets, beta)
+        return da, dp, dls, None, None
+
+
+class _SigLipFn(torch.autograd.Function):
+    """src/coordination.py:76-95 (+ beta * MSE of :108-112 when beta != 0)."""
+
+    @staticmethod
+    def forward(ctx, image_emb, profile_emb, logit_scale, bias, buckets, beta):
+        a, p, u, v, iu, iv, S, n = _prep(image_emb, profile_emb, buckets)
+        dev = a.device
+        loss = torch.empty((), dtype=F32, device=dev)
+        N.call('mpr_siglip_fwd', S, logit_scale.detach(), bias.detach(), loss, _workspace(dev), buckets, n)
+        if beta:
+            N.call('mpr_mse_add', a, p, float(beta), loss, _workspace(dev), a.numel())
+        ctx.save_for_backward(a, p, u, v, iu, iv, S, logit_scale, bias)
+        ctx.cfg = (n, buckets, beta)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, p, u, v, iu, iv, S, logit_scale, bias = ctx.saved_tensors
+        n, buckets, beta = ctx.cfg
+        gout = gout.contiguous().float()
+        dls = torch.empty((), dtype=F32, device=a.device)
+        db = torch.empty((), dtype=F32, device=a.device)
+        G = S.clone()
+        N.call('mpr_siglip_bwd', G, logit_scale.detach(), bias.detach(), gout, dls, db, _workspace(a.device), buckets, n)
+        da, dp = _embedding_grads(ctx, G, gout, a, p, u, v, iu, iv, n, buckets, beta)
+        return da, dp, dls, db, None, None
+
+
+def retrieval_top1(image_emb: Tensor, profile_emb: Tensor):
+    """int64 argmax_j cos(u_i, v_j) per image row and argmax_i per profile column (first maximum
+    wins, as torch.argmax) -- the retrieval 'class indices' of the parity contract."""
+    a, p, u, v, iu, iv, S, n = _prep(image_emb, profile_emb, 1)
+    St = ops.gemm(v, u, trans_b=True)
+    _, rows, _ = ops.softmax_ce(S.view(n, n))
+    _, cols, _ = ops.softmax_ce(St)
+    return rows, cols
+
+
+class CLIPLoss(nn.Module):
+    """Reference: src/coordination.py:17-47.  ``logit_scale`` starts at 1 (multiplier e), learnable."""
+
+    def __init__(self, bias: bool = False) -> None:
+        super().__init__()
+        self.logit_scale = Parameter(torch.ones([]))
+
+    def forward(self, image_emb: Tensor, profile_emb: Tensor, buckets: int = 1) -> Tensor:
+        return _ClipFn.apply(image_emb, profile_emb, self.logit_scale, int(buckets), 0.0)
+
+
+class CLIPPlus(nn.Module):
+    """Reference: src/coordination.py:50-64 (state_dict key ``clip.logit_scale``)."""
+
+    def __init__(self, beta: float = 0.25) -> None:
+        super().__init__()
+        self.clip = CLIPLoss()
+        self.beta = beta
+
+    def forward(self, image_emb: Tensor, profile_emb: Tensor, buckets: int = 1) -> Tensor:
+        return _ClipFn.apply(image_emb, profile_emb, self.clip.logit_scale, int(buckets), float(self.beta))
+
+
+class SigLIPLoss(nn.Module):
+    """Reference: src/coordination.py:67-95 (logit_scale 1, bias -10)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.logit_scale = Parameter(torch.ones([]))
+        self.bias = Parameter(-10 * torch.ones([]))
+
+    def forward(self, image_emb: Tensor, profile_emb: Tensor, buckets: int = 1) -> Tensor:
+        return _SigLipFn.apply(image_emb, profile_emb, self.logit_scale, self.bias, int(buckets), 0.0)
+
+
+class SigLIPPlus(nn.Module):
+    """Reference: src/coordination.py:98-112 (state_dict keys ``siglip.{logit_scale,bias}``)."""
+
+    def __init__(self, beta: float = 0.25) -> None:
+        super().__init__()
+        self.siglip = SigLIPLoss()
+        self.beta = beta
+
+    def forward(self, image_emb: Tensor, profile_emb: Tensor, buckets: int = 1) -> Tensor:
+        return _SigLipFn.apply(image_emb, profile_emb, self.siglip.logit_scale, self.siglip.bias, int(buckets),
+                               float(self.beta))
+
+
+class RankLoss(nn.Module):
+    """Reference: src/coordination.py:115-135.  As in the reference, ``forward`` has no ``buckets``
+    parameter, so ``MultiModel.training_step`` (which passes ``buckets``) raises TypeError for
+    ``method: rank`` -- kept on purpose.  No native kernel yet: direct calls raise."""
+
+    def __init__(self, margin: float) -> None:
+        super().__init__()
+        self.margin = margin
+
+    def forward(self, image_emb: Tensor, profile_emb: Tensor) -> Tensor:
+        raise NotImplementedError('RankLoss: native gfx950 kernel not built yet (no torch fallback)')

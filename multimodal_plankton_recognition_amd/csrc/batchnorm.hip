@@ -1,0 +1,341 @@
+// Train-mode BatchNorm (1-D and 2-D are the same thing on channels-last [rows][C] bf16 tensors),
+// forward and backward, HBM-bound: every pass moves 16 B per lane, channel group fixed per thread.
+//   forward : statistics come fused from the producing conv's epilogue (partial sums) ->
+//             bn_finalize_stats (mean/var -> scale/shift, running-stat update) -> bn_apply
+//             (y = [relu](x*scale + shift [+ residual])).
+//   backward: bn_bwd_reduce (sum dz, sum dz*xhat, dz = dy * relu-mask) -> bn_bwd_finalize
+//             (dgamma, dbeta, per-channel coefficients) -> bn_bwd_apply (dx = k1*dz + k2*x + k3).
+// Semantics follow torch.nn.BatchNorm{1,2}d defaults used by the reference
+// (src/profile_encoder.py:126,129,168; timm ResNet): biased variance for normalisation, unbiased for
+// running_var, momentum 0.1, eps 1e-5.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// partials [nparts][2][C] -> per-channel scale/shift (+ saved mean / invstd, running-stat update)
+__global__ __launch_bounds__(1024) void bn_finalize_stats_kernel(
+    const float* __restrict__ partials, int nparts, float count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+    float* __restrict__ invstd_out, int C) {
+  __shared__ double red[2][32][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int i = pl; i < nparts; i += 32) {
+      s1 += (double)partials[((size_t)i * 2) * C + c];
+      s2 += (double)partials[((size_t)i * 2 + 1) * C + c];
+    }
+  red[0][pl][threadIdx.x & 31] = s1;
+  red[1][pl][threadIdx.x & 31] = s2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    for (int i = 1; i < 32; ++i) { s1 += red[0][i][threadIdx.x]; s2 += red[1][i][threadIdx.x]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = b - (float)mean * g * invstd;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    if (running_mean) {
+      const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+// eval-mode coefficients from the running statistics
+__global__ void bn_eval_coefs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                     float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float s = gamma[c] / sqrtf(rv[c] + eps);   // exact 1/sqrt: stays close to the fp32 oracle
+    scale[c] = s;
+    shift[c] = beta[c] - rm[c] * s;
+  }
+}
+
+// standalone statistics pass (for producers without a fused epilogue): partials [grid][2][C]
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partials,
+                                                       long long nvec, int C) {
+  const int cg = C >> 3;
+  __shared__ float red[256][17];
+  const int nthr = blockDim.x;
+  const int g = threadIdx.x % cg;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (long long v = (long long)blockIdx.x * nthr + threadIdx.x; v < nvec; v += (long long)gridDim.x * nthr) {
+    float f[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[v], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cg * 16; i += nthr) {
+    const int gg = i >> 4, e = i & 15;
+    float a = 0.f;
+    for (int t = gg; t < nthr; t += cg) a += red[t][e];
+    partials[((size_t)blockIdx.x * 2 + (e >> 3)) * C + gg * 8 + (e & 7)] = a;
+  }
+  (void)g;
+}
+
+// y = [relu](x*scale + shift [+ res])
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const bf16_t* __restrict__ res, bf16_t* __restrict__ y,
+                                                       long long nvec, int cg) {
+  // blockDim is a multiple of cg (host guarantees): the channel group is thread-invariant
+  const int g = threadIdx.x % cg;
+  float sc[8], sh[8];
+  *reinterpret_cast<float4*>(sc) = reinterpret_cast<const float4*>(scale)[g * 2];
+  *reinterpret_cast<float4*>(sc + 4) = reinterpret_cast<const float4*>(scale)[g * 2 + 1];
+  *reinterpret_cast<float4*>(sh) = reinterpret_cast<const float4*>(shift)[g * 2];
+  *reinterpret_cast<float4*>(sh + 4) = reinterpret_cast<const float4*>(shift)[g * 2 + 1];
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+       v += (long long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[v], f);
+    float r[8];
+    if (RES) unpack8(reinterpret_cast<const uint4*>(res)[v], r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = fmaf(f[e], sc[e], sh[e]);
+      if (RES) t += r[e];
+      if (RELU) t = fmaxf(t, 0.f);
+      f[e] = t;
+    }
+    reinterpret_cast<uint4*>(y)[v] = pack8(f);
+  }
+}
+
+// mask modes for the backward passes
+enum { MASK_NONE = 0, MASK_Y = 1, MASK_RECOMPUTE = 2 };
+
+template <int MODE>
+__device__ __forceinline__ void masked_dz(const uint4* dy, const uint4* ymask, const float* xf, const float* sc,
+                                          const float* sh, long long v, float* dz) {
+  unpack8(dy[v], dz);
+  if (MODE == MASK_Y) {
+    float yv[8];
+    unpack8(ymask[v], yv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dz[e] = yv[e] > 0.f ? dz[e] : 0.f;
+  } else if (MODE == MASK_RECOMPUTE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dz[e] = round_bf16(fmaf(xf[e], sc[e], sh[e])) > 0.f ? dz[e] : 0.f;
+  }
+}
+
+// partials [grid][2][C]: sum dz, sum dz*xhat
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ ymask, const bf16_t* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ partials, long long nvec, int C) {
+  const int cg = C >> 3;
+  __shared__ float red[256][17];
+  const int nthr = blockDim.x;   // a multiple of cg (host guarantees), so the channel group is thread-invariant
+  const int g = threadIdx.x % cg;
+  float mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = mean[g * 8 + e];
+    is[e] = invstd[g * 8 + e];
+    sc[e] = MODE == MASK_RECOMPUTE ? scale[g * 8 + e] : 0.f;
+    sh[e] = MODE == MASK_RECOMPUTE ? shift[g * 8 + e] : 0.f;
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (long long v = (long long)blockIdx.x * nthr + threadIdx.x; v < nvec; v += (long long)gridDim.x * nthr) {
+    float xf[8], dz[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[v], xf);
+    masked_dz<MODE>(reinterpret_cast<const uint4*>(dy), reinterpret_cast<const uint4*>(ymask), xf, sc, sh, v, dz);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s1[e] += dz[e];
+      s2[e] += dz[e] * (xf[e] - mu[e]) * is[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cg * 16; i += nthr) {
+    const int gg = i >> 4, e = i & 15;
+    float a = 0.f;
+    for (int t = gg; t < nthr; t += cg) a += red[t][e];
+    partials[((size_t)blockIdx.x * 2 + (e >> 3)) * C + gg * 8 + (e & 7)] = a;
+  }
+}
+
+// partials -> dgamma, dbeta, coef[3][C] with dx = coef0*dz + coef1*x + coef2
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partials, int nparts, float count, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int accumulate, float* __restrict__ coef, int C) {
+  __shared__ double red[2][32][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int i = pl; i < nparts; i += 32) {
+      s1 += (double)partials[((size_t)i * 2) * C + c];
+      s2 += (double)partials[((size_t)i * 2 + 1) * C + c];
+    }
+  red[0][pl][threadIdx.x & 31] = s1;
+  red[1][pl][threadIdx.x & 31] = s2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    for (int i = 1; i < 32; ++i) { s1 += red[0][i][threadIdx.x]; s2 += red[1][i][threadIdx.x]; }
+    const float sum_dz = (float)s1, sum_dzx = (float)s2;
+    const float g = gamma ? gamma[c] : 1.f, is = invstd[c], mu = mean[c];
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sum_dzx : sum_dzx;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sum_dz : sum_dz;
+    const float k1 = g * is;
+    const float k2 = -g * is * is * sum_dzx / count;
+    const float k3 = -g * is * sum_dz / count - k2 * mu;
+    coef[c] = k1;
+    coef[C + c] = k2;
+    coef[2 * C + c] = k3;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ ymask, const bf16_t* __restrict__ x,
+    const float* __restrict__ coef, const float* __restrict__ scale, const float* __restrict__ shift,
+    bf16_t* __restrict__ dx, bf16_t* __restrict__ dz_out, long long nvec, int C) {
+  const int cg = C >> 3;
+  const int g = threadIdx.x % cg;   // blockDim is a multiple of cg
+  float k1[8], k2[8], k3[8], sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    k1[e] = coef[g * 8 + e];
+    k2[e] = coef[C + g * 8 + e];
+    k3[e] = coef[2 * C + g * 8 + e];
+    sc[e] = MODE == MASK_RECOMPUTE ? scale[g * 8 + e] : 0.f;
+    sh[e] = MODE == MASK_RECOMPUTE ? shift[g * 8 + e] : 0.f;
+  }
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+       v += (long long)gridDim.x * blockDim.x) {
+    float xf[8], dz[8], o[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[v], xf);
+    masked_dz<MODE>(reinterpret_cast<const uint4*>(dy), reinterpret_cast<const uint4*>(ymask), xf, sc, sh, v, dz);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(k1[e], dz[e], fmaf(k2[e], xf[e], k3[e]));
+    reinterpret_cast<uint4*>(dx)[v] = pack8(o);
+    if (dz_out) reinterpret_cast<uint4*>(dz_out)[v] = pack8(dz);
+  }
+}
+
+static inline int ew_grid(long long nvec, int block) {
+  long long g = (nvec + block - 1) / block;
+  return (int)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
+}
+static inline int cg_block(int cg) { return (256 / cg) * cg; }
+
+extern "C" {
+
+int mpr_bn_reduce_rows(long long rows, int C) {   // rows of the partial buffers used by bn_stats / bn_bwd_reduce
+  const long long nvec = rows * C / 8;
+  return ew_grid(nvec, cg_block(C / 8));
+}
+
+int mpr_bn_stats(const void* x, float* partials, long long rows, int C, void* stream) {
+  MPR_REQUIRE(C % 8 == 0 && C / 8 <= 256, "mpr_bn_stats: C must be a multiple of 8, <= 2048 (got %d)", C);
+  const long long nvec = rows * C / 8;
+  const int block = cg_block(C / 8);
+  bn_stats_kernel<<<ew_grid(nvec, block), block, 0, (hipStream_t)stream>>>((const bf16_t*)x, partials, nvec, C);
+  MPR_LAUNCH_CHECK("bn_stats_kernel");
+  return MPR_OK;
+}
+
+int mpr_bn_finalize_stats(const float* partials, int nparts, long long count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                          float* scale, float* shift, float* mean, float* invstd, int C, void* stream) {
+  MPR_REQUIRE(partials && scale && shift && mean && invstd, "mpr_bn_finalize_stats: null pointer");
+  bn_finalize_stats_kernel<<<ceil_div(C, 32), 1024, 0, (hipStream_t)stream>>>(
+      partials, nparts, (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean,
+      invstd, C);
+  MPR_LAUNCH_CHECK("bn_finalize_stats_kernel");
+  return MPR_OK;
+}
+
+int mpr_bn_eval_coefs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float* scale, float* shift, int C, void* stream) {
+  bn_eval_coefs_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var,
+                                                                          eps, scale, shift, C);
+  MPR_LAUNCH_CHECK("bn_eval_coefs_kernel");
+  return MPR_OK;
+}
+
+int mpr_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, int relu, void* y,
+                 long long rows, int C, void* stream) {
+  MPR_REQUIRE(C % 8 == 0, "mpr_bn_apply: C must be a multiple of 8 (got %d)", C);
+  MPR_REQUIRE(C / 8 <= 256, "mpr_bn_apply: C must be <= 2048");
+  const long long nvec = rows * C / 8;
+  const int BLK = cg_block(C / 8), grid = ew_grid(nvec, BLK);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t *xp = (const bf16_t*)x, *rp = (const bf16_t*)residual;
+  bf16_t* yp = (bf16_t*)y;
+  if (relu && rp) bn_apply_kernel<true, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8);
+  else if (relu) bn_apply_kernel<true, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8);
+  else if (rp) bn_apply_kernel<false, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8);
+  else bn_apply_kernel<false, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8);
+  MPR_LAUNCH_CHECK("bn_apply_kernel");
+  return MPR_OK;
+}
+
+// mask_mode: 0 none, 1 relu mask from y (y > 0), 2 recompute relu mask from x*scale+shift
+int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                      const float* scale, const float* shift, int mask_mode, float* partials, long long rows,
+                      int C, void* stream) {
+  MPR_REQUIRE(C % 8 == 0 && C / 8 <= 256, "mpr_bn_bwd_reduce: C must be a multiple of 8, <= 2048 (got %d)", C);
+  MPR_REQUIRE(mask_mode != MASK_Y || y, "mpr_bn_bwd_reduce: mask_mode 1 needs y");
+  const long long nvec = rows * C / 8;
+  const int block = cg_block(C / 8), grid = ew_grid(nvec, block);
+  hipStream_t st = (hipStream_t)stream;
+#define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, partials, nvec, C
+  if (mask_mode == MASK_NONE) bn_bwd_reduce_kernel<MASK_NONE><<<grid, block, 0, st>>>(ARGS);
+  else if (mask_mode == MASK_Y) bn_bwd_reduce_kernel<MASK_Y><<<grid, block, 0, st>>>(ARGS);
+  else bn_bwd_reduce_kernel<MASK_RECOMPUTE><<<grid, block, 0, st>>>(ARGS);
+#undef ARGS
+  MPR_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+  return MPR_OK;
+}
+
+int mpr_bn_bwd_finalize(const float* partials, int nparts, long long count, const float* gamma, const float* mean,
+                        const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef, int C,
+                        void* stream) {
+  bn_bwd_finalize_kernel<<<ceil_div(C, 32), 1024, 0, (hipStream_t)stream>>>(
+      partials, nparts, (float)count, gamma, mean, invstd, dgamma, dbeta, accumulate, coef, C);
+  MPR_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+  return MPR_OK;
+}
+
+int mpr_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coef, const float* scale,
+                     const float* shift, int mask_mode, void* dx, void* dz_out, long long rows, int C,
+                     void* stream) {
+  MPR_REQUIRE(C % 8 == 0, "mpr_bn_bwd_apply: C must be a multiple of 8 (got %d)", C);
+  MPR_REQUIRE(C / 8 <= 256, "mpr_bn_bwd_apply: C must be <= 2048");
+  const long long nvec = rows * C / 8;
+  const int BLK = cg_block(C / 8), grid = ew_grid(nvec, BLK);
+  hipStream_t st = (hipStream_t)stream;
+#define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, coef, scale, shift, (bf16_t*)dx, (bf16_t*)dz_out, nvec, C
+  if (mask_mode == MASK_NONE) bn_bwd_apply_kernel<MASK_NONE><<<grid, BLK, 0, st>>>(ARGS);
+  else if (mask_mode == MASK_Y) bn_bwd_apply_kernel<MASK_Y><<<grid, BLK, 0, st>>>(ARGS);
+  else bn_bwd_apply_kernel<MASK_RECOMPUTE><<<grid, BLK, 0, st>>>(ARGS);
+#undef ARGS
+  MPR_LAUNCH_CHECK("bn_bwd_apply_kernel");
+  return MPR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,352 @@
+// Implicit-GEMM convolution, forward and data-gradient, bf16 NHWC in / fp32 MFMA accumulate.
+//
+// Replaces the cuDNN/MIOpen calls behind timm's ResNet convs (reference call site
+// src/image_encoder.py:24) and nn.Conv1d in ProfileCNN (src/profile_encoder.py:125-128,167,187)
+// -- a 1-D conv is the H == 1 case.
+//
+// GEMM view (rows = pixels of the tensor being produced, cols = its channels):
+//   forward : y[m = (b,p,q)][n = k]  = sum_{r,s,c} x [b, p*st-pad+r, q*st-pad+s, c] * Wf[k][(r,s,c)]
+//   dgrad   : dx[m = (b,h,w)][n = c] = sum_{r,s,k} dy[b, (h+pad-r)/st, (w+pad-s)/st, k] * Wd[c][(r,s,k)]
+// A rows are gathered on the fly (zero for padding taps / stride holes), B is a pre-packed
+// [N][Kg] bf16 panel (K contiguous, zero padded to 64).  One workgroup = 4 waves, each wave owns a
+// 64x64 output block as 2x2 v_mfma_f32_32x32x16_bf16 tiles; WG tile = (64*WM) x (64*WN).
+// K advances in 64-element (128 B) chunks: global -> VGPR (issued before the MFMAs of the current
+// chunk) -> XOR-swizzled LDS (written after them), double buffered, one barrier per chunk.
+// The MFMA is issued "swapped" (weights as the A operand) so that a lane ends up with 4 consecutive
+// channels of one pixel; the epilogue stages the fp32 tile in LDS, then writes whole 16-B channel
+// groups, fusing (a) per-channel sum / sum-of-squares partials for train-mode BatchNorm and (b) an
+// optional residual add (the skip-connection gradient in dgrad).
+#include "common.h"
+
+struct ConvGemmParams {
+  const bf16_t* src;   // fwd: x [B,sH,sW,sC];  dgrad: dy [B,sH,sW,sC]
+  const bf16_t* wpk;   // [Npad][Kgpad]
+  bf16_t* dst;         // [M][Nout]
+  const bf16_t* add;   // optional [M][Nout]
+  float* stats;        // optional [gridM][2][Nout]
+  int sH, sW, sC;
+  int M, Nout, Kg, Kgpad, nk, ntn;
+  int R, S, sh, sw, ph, pw;
+  FastDiv div_pq, div_q;   // row m -> (b, p, q)
+  int Pm, Qm;
+};
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {   // byte offset in a [rows][128 B] tile
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <int WM, int WN, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGemmParams p) {
+  constexpr int BM = WM * 64, BN = WN * 64;
+  constexpr int A_IT = BM / 32, B_IT = BN / 32;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int CS_STRIDE = BN * 4 + 16;   // fp32 epilogue tile row stride (bytes)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / p.ntn, nt = bid - mt * p.ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-thread gather coordinates (fixed over K)
+  const int c8 = tid & 7, r0 = tid >> 3;
+  int rbase[A_IT], rh[A_IT], rw[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (m < p.M) {
+      uint32_t b = fdiv(m, p.div_pq);
+      uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
+      uint32_t pp = fdiv(rem, p.div_q);
+      uint32_t qq = rem - pp * p.Qm;
+      rbase[i] = b * p.sH * p.sW;
+      if (!DGRAD) { rh[i] = (int)pp * p.sh - p.ph; rw[i] = (int)qq * p.sw - p.pw; }
+      else        { rh[i] = (int)pp + p.ph;        rw[i] = (int)qq + p.pw; }
+    } else {
+      rbase[i] = 0; rh[i] = -(1 << 20); rw[i] = -(1 << 20);
+    }
+  }
+  // tap tracking for this thread's 8-channel segment: k = kc*64 + c8*8 -> (r, s, c)
+  int tc, tr, ts;
+  {
+    int k = c8 * 8;
+    int t = k / p.sC;
+    tc = k - t * p.sC;
+    tr = t / p.S;
+    ts = t - tr * p.S;
+  }
+  const bf16_t* wrow = p.wpk + (size_t)(n0 + r0) * p.Kgpad + c8 * 8;
+
+  uint4 areg[A_IT], breg[B_IT];
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      bool ok;
+      int off;
+      if (!DGRAD) {
+        int ih = rh[i] + tr, iw = rw[i] + ts;
+        ok = (unsigned)ih < (unsigned)p.sH && (unsigned)iw < (unsigned)p.sW && tr < p.R;
+        off = (rbase[i] + ih * p.sW + iw) * p.sC + tc;
+      } else {
+        int oh = rh[i] - tr, ow = rw[i] - ts;
+        ok = oh >= 0 && ow >= 0 && tr < p.R;
+        if (p.sh == 2) { ok = ok && !(oh & 1); oh >>= 1; }
+        if (p.sw == 2) { ok = ok && !(ow & 1); ow >>= 1; }
+        ok = ok && oh < p.sH && ow < p.sW;
+        off = (rbase[i] + oh * p.sW + ow) * p.sC + tc;
+      }
+      areg[i] = ok ? *reinterpret_cast<const uint4*>(p.src + off) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      breg[i] = *reinterpret_cast<const uint4*>(wrow + (size_t)(32 * i) * p.Kgpad + kc * 64);
+    // advance the tap by one 64-element chunk
+    tc += 64;
+    while (tc >= p.sC) { tc -= p.sC; if (++ts == p.S) { ts = 0; ++tr; } }
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned char* a = smem + buf * STAGE;
+    unsigned char* b = a + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(a + swz_off(r0 + 32 * i, c8)) = areg[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(b + swz_off(r0 + 32 * i, c8)) = breg[i];
+  };
+
+  f32x16 acc[2][2];   // [ntile][mtile], D'[n][m]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int kc = 0; kc < p.nk; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < p.nk) load_chunk(kc + 1);
+    const unsigned char* a = smem + cur * STAGE;
+    const unsigned char* b = a + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = *reinterpret_cast<const bf16x8*>(a + swz_off(wm * 64 + t * 32 + frow, ks * 2 + fh));
+        bfr[t] = *reinterpret_cast<const bf16x8*>(b + swz_off(wn * 64 + t * 32 + frow, ks * 2 + fh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < p.nk) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: fp32 tile -> LDS -> 16-B channel groups (+ residual, + BN partial sums)
+  // lane holds, for pixel m = lane&31, channels n = 8g + 4*(lane>>5) + (0..3) in acc regs 4g..4g+3
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wm * 64 + j * 32 + frow;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wn * 64 + i * 32 + 8 * g + 4 * fh;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
+      }
+    }
+  __syncthreads();
+
+  constexpr int CPR = BN / 8;          // 16-B output chunks per tile row
+  constexpr int RPP = 256 / CPR;       // rows per pass
+  const int ch = tid % CPR, rr = tid / CPR;
+  const int ncol = n0 + ch * 8;
+  const bool col_ok = ncol < p.Nout;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll 4
+  for (int r = rr; r < BM; r += RPP) {
+    const int m = m0 + r;
+    if (m < p.M && col_ok) {
+      const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
+      const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
+      float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const size_t o = (size_t)m * p.Nout + ncol;
+      if (p.add) {
+        float g[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.add + o), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += g[e];
+      }
+      const uint4 pk = pack8(f);
+      *reinterpret_cast<uint4*>(p.dst + o) = pk;
+      if (p.stats) {
+        float q[8];
+        unpack8(pk, q);   // statistics of the values BatchNorm will actually read
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+      }
+    }
+  }
+  if (p.stats) {
+    // threads with equal `ch` are CPR lanes apart inside a wave; fold them, then fold the 4 waves
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][CPR][16]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wid * CPR + lane) * 16 + e] = s1[e];
+        red[(wid * CPR + lane) * 16 + 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < CPR * 16) {
+      const int c = tid >> 4, e = tid & 15;
+      const float v = red[(0 * CPR + c) * 16 + e] + red[(1 * CPR + c) * 16 + e] +
+                      red[(2 * CPR + c) * 16 + e] + red[(3 * CPR + c) * 16 + e];
+      const int n = n0 + c * 8 + (e & 7);
+      if (n < p.Nout) p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing:  OIHW fp32  ->  Wf [Kpad128][ceil64(R*S*C)]  and  Wd [Cpad128][ceil64(R*S*K)]  bf16
+__global__ void conv_pack_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf,
+                                         bf16_t* __restrict__ wd, int K, int C, int R, int S,
+                                         int KgF, int KgFpad, int NpadF, int KgD, int KgDpad, int NpadD) {
+  const int totalF = NpadF * KgFpad, totalD = wd ? NpadD * KgDpad : 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < totalF + totalD; i += gridDim.x * blockDim.x) {
+    if (i < totalF) {
+      const int k = i / KgFpad, g = i - k * KgFpad;
+      float v = 0.f;
+      if (k < K && g < KgF) {
+        const int t = g / C, c = g - t * C, r = t / S, s = t - r * S;
+        v = w[((size_t)(k * C + c) * R + r) * S + s];
+      }
+      wf[i] = (bf16_t)v;
+    } else {
+      const int j = i - totalF;
+      const int c = j / KgDpad, g = j - c * KgDpad;
+      float v = 0.f;
+      if (c < C && g < KgD) {
+        const int t = g / K, k = g - t * K, r = t / S, s = t - r * S;
+        v = w[((size_t)(k * C + c) * R + r) * S + s];
+      }
+      wd[j] = (bf16_t)v;
+    }
+  }
+}
+
+static inline int pad_to(int x, int a) { return (x + a - 1) / a * a; }
+
+extern "C" {
+
+// Sizes (in bf16 elements) of the packed panels for a [K,C,R,S] filter.
+int mpr_conv_packed_sizes(int K, int C, int R, int S, long long* fwd_elems, long long* dgrad_elems) {
+  if (fwd_elems) *fwd_elems = (long long)pad_to(K, 128) * pad_to(R * S * C, 64);
+  if (dgrad_elems) *dgrad_elems = (long long)pad_to(C, 128) * pad_to(R * S * K, 64);
+  return MPR_OK;
+}
+
+int mpr_conv_pack_weights(const float* w_oihw, void* w_fwd, void* w_dgrad, int K, int C, int R, int S,
+                          void* stream) {
+  MPR_REQUIRE(w_oihw && w_fwd, "mpr_conv_pack_weights: null pointer");
+  const int KgF = R * S * C, KgD = R * S * K;
+  const int total = pad_to(K, 128) * pad_to(KgF, 64) + (w_dgrad ? pad_to(C, 128) * pad_to(KgD, 64) : 0);
+  const int grid = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
+  conv_pack_weights_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
+      w_oihw, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, K, C, R, S, KgF, pad_to(KgF, 64), pad_to(K, 128), KgD,
+      pad_to(KgD, 64), pad_to(C, 128));
+  MPR_LAUNCH_CHECK("conv_pack_weights_kernel");
+  return MPR_OK;
+}
+
+static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
+  // tile choice: N <= 64 -> 256x64 (all four waves along M), else 128x128
+  const bool narrow = p.Nout <= 64;
+  const int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
+  p.ntn = ceil_div(p.Nout, BN);
+  const int gm = ceil_div(p.M, BM);
+  const size_t stage2 = (size_t)2 * (BM + BN) * 128, epi = (size_t)BM * (BN * 4 + 16);
+  const size_t smem = stage2 > epi ? stage2 : epi;
+  dim3 grid(gm * p.ntn);
+#define MPR_IGEMM(WM_, WN_, DG_)                                                                      \
+  do {                                                                                                \
+    static bool attr_set = false;                                                                     \
+    if (!attr_set) {                                                                                  \
+      hipFuncSetAttribute((const void*)conv_igemm_kernel<WM_, WN_, DG_>,                              \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                     \
+      attr_set = true;                                                                                \
+    }                                                                                                 \
+    conv_igemm_kernel<WM_, WN_, DG_><<<grid, 256, smem, st>>>(p);                                     \
+  } while (0)
+  if (narrow) { if (dgrad) MPR_IGEMM(4, 1, true); else MPR_IGEMM(4, 1, false); }
+  else        { if (dgrad) MPR_IGEMM(2, 2, true); else MPR_IGEMM(2, 2, false); }
+#undef MPR_IGEMM
+  MPR_LAUNCH_CHECK("conv_igemm_kernel");
+  return MPR_OK;
+}
+
+// Number of row tiles (= rows of the BatchNorm partial-sum buffer) mpr_conv_fwd will use.
+int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K) {
+  return ceil_div(B * P * Q, K <= 64 ? 256 : 128);
+}
+
+// y[B,P,Q,K] = conv(x[B,H,W,C], w) ; stats (optional): [mpr_conv_fwd_stat_rows][2][K] fp32 partial sums
+int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B, int H, int W, int C,
+                 int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+  MPR_REQUIRE(x && w_fwd && y, "mpr_conv_fwd: null pointer");
+  MPR_REQUIRE(C % 8 == 0 && K % 8 == 0, "mpr_conv_fwd: C (%d) and K (%d) must be multiples of 8", C, K);
+  MPR_REQUIRE(sh >= 1 && sw >= 1 && R >= 1 && S >= 1 && ph >= 0 && pw >= 0, "mpr_conv_fwd: bad geometry");
+  const int P = (H + 2 * ph - R) / sh + 1, Q = (W + 2 * pw - S) / sw + 1;
+  MPR_REQUIRE(P > 0 && Q > 0, "mpr_conv_fwd: empty output");
+  MPR_REQUIRE((long long)B * H * W * C < (1ll << 31) && (long long)B * P * Q * K < (1ll << 31),
+              "mpr_conv_fwd: tensor exceeds 2^31 elements");
+  ConvGemmParams p;
+  p.src = (const bf16_t*)x; p.wpk = (const bf16_t*)w_fwd; p.dst = (bf16_t*)y; p.add = nullptr; p.stats = stats;
+  p.sH = H; p.sW = W; p.sC = C;
+  p.M = B * P * Q; p.Nout = K; p.Kg = R * S * C; p.Kgpad = pad_to(p.Kg, 64); p.nk = p.Kgpad / 64;
+  p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
+  p.Pm = P; p.Qm = Q; p.div_pq = make_fastdiv(P * Q); p.div_q = make_fastdiv(Q);
+  return launch_igemm(false, p, (hipStream_t)stream);
+}
+
+// dx[B,H,W,C] = conv_transpose(dy[B,P,Q,K], w) (+ add[B,H,W,C] if given)
+int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add, int B, int H, int W,
+                   int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+  MPR_REQUIRE(dy && w_dgrad && dx, "mpr_conv_dgrad: null pointer");
+  MPR_REQUIRE(C % 8 == 0 && K % 8 == 0, "mpr_conv_dgrad: C (%d) and K (%d) must be multiples of 8", C, K);
+  MPR_REQUIRE((sh == 1 || sh == 2) && (sw == 1 || sw == 2), "mpr_conv_dgrad: strides must be 1 or 2 (got %d,%d)", sh, sw);
+  const int P = (H + 2 * ph - R) / sh + 1, Q = (W + 2 * pw - S) / sw + 1;
+  MPR_REQUIRE(P > 0 && Q > 0, "mpr_conv_dgrad: empty output");
+  MPR_REQUIRE((long long)B * H * W * C < (1ll << 31) && (long long)B * P * Q * K < (1ll << 31),
+              "mpr_conv_dgrad: tensor exceeds 2^31 elements");
+  ConvGemmParams p;
+  p.src = (const bf16_t*)dy; p.wpk = (const bf16_t*)w_dgrad; p.dst = (bf16_t*)dx; p.add = (const bf16_t*)add;
+  p.stats = nullptr;
+  p.sH = P; p.sW = Q; p.sC = K;
+  p.M = B * H * W; p.Nout = C; p.Kg = R * S * K; p.Kgpad = pad_to(p.Kg, 64); p.nk = p.Kgpad / 64;
+  p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
+  p.Pm = H; p.Qm = W; p.div_pq = make_fastdiv(H * W); p.div_q = make_fastdiv(W);
+  return launch_igemm(true, p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// Stem convolutions with a tiny input-channel count (ResNet-18 conv1: 1 -> 64, 7x7/2;
+// ProfileCNN conv1: 6 -> base, k3/2, src/profile_encoder.py:167).  K = Cin*R*S is 49 / 18 taps,
+// so these layers are bound by the bytes of their OUTPUT (822 MB of bf16 at batch 512), not by math:
+// a direct fp32 convolution from the fp32 input, 8 output channels per lane so that each pixel's
+// channel vector leaves as 16-B stores, with the BatchNorm partial sums fused in.  No dgrad is
+// needed (the input is data).  The weight gradient is a long skinny reduction over pixels.
+#include "common.h"
+
+#define STEM_MAX_TAPS 64
+
+struct StemGeom {
+  int B, H, W, Cin, K, R, S, sh, sw, ph, pw, P, Q, taps;
+};
+
+// x [B,H,W,Cin] fp32 (Cin == 1: identical to NCHW), w [K][Cin][R][S] fp32 (torch OIHW)
+// y [B,P,Q,K] bf16, partials [grid][2][K]
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       bf16_t* __restrict__ y, float* __restrict__ partials,
+                                                       StemGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [taps][K]  (tap = (c, r, s))
+  __shared__ float red[256][17];
+  const int cgn = g.K >> 3;
+  const int nthr = blockDim.x;
+  for (int i = threadIdx.x; i < g.taps * g.K; i += nthr) {
+    const int t = i / g.K, k = i - t * g.K;
+    wl[i] = w[(size_t)k * g.taps + t];
+  }
+  __syncthreads();
+  const int cg = threadIdx.x % cgn;
+  const int ppb = nthr / cgn;                       // pixels per block pass
+  const int pl = threadIdx.x / cgn;
+  const int npix = g.B * g.P * g.Q;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (int pix = blockIdx.x * ppb + pl; pix < npix; pix += gridDim.x * ppb) {
+    const int q = pix % g.Q;
+    int t = pix / g.Q;
+    const int p = t % g.P;
+    const int b = t / g.P;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int r = 0; r < g.R; ++r) {
+      const int ih = p * g.sh - g.ph + r;
+      if ((unsigned)ih >= (unsigned)g.H) continue;
+      for (int s = 0; s < g.S; ++s) {
+        const int iw = q * g.sw - g.pw + s;
+        if ((unsigned)iw >= (unsigned)g.W) continue;
+        const float* xp = x + (((size_t)b * g.H + ih) * g.W + iw) * g.Cin;
+        for (int c = 0; c < g.Cin; ++c) {
+          const float xv = xp[c];
+          const float* wp = wl + ((c * g.R + r) * g.S + s) * g.K + cg * 8;
+          const float4 w0 = *reinterpret_cast<const float4*>(wp);
+          const float4 w1 = *reinterpret_cast<const float4*>(wp + 4);
+          acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]);
+          acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
+          acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]);
+          acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
+        }
+      }
+    }
+    const uint4 pk = pack8(acc);
+    reinterpret_cast<uint4*>(y)[(size_t)pix * cgn + cg] = pk;
+    if (partials) {
+      float f[8];
+      unpack8(pk, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+    }
+  }
+  if (partials) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cgn * 16; i += nthr) {
+      const int gg = i >> 4, e = i & 15;
+      float a = 0.f;
+      for (int t = gg; t < nthr; t += cgn) a += red[t][e];
+      partials[((size_t)blockIdx.x * 2 + (e >> 3)) * g.K + gg * 8 + (e & 7)] = a;
+    }
+  }
+}
+
+// dw[k][tap] += sum_pix dy[pix][k] * x[pix @ tap]   (dw zeroed by the host wrapper; fp32 atomics, one per
+// (block, element)).  Thread = (8 output channels) x (a strided subset of the taps).
+template <int MAXT>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                         float* __restrict__ dw, StemGeom g, int pix_per_block) {
+  const int cgn = g.K >> 3;
+  const int nthr = blockDim.x;
+  const int cg = threadIdx.x % cgn;
+  const int tl = threadIdx.x / cgn, ntl = nthr / cgn;      // tap lane
+  // MAXT = taps per thread (host guarantees taps <= ntl*MAXT)
+  int tc[MAXT], trr[MAXT], tss[MAXT];
+  bool tv[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int t = tl + j * ntl;
+    tv[j] = t < g.taps;
+    const int tt = tv[j] ? t : 0;
+    tc[j] = tt / (g.R * g.S);
+    const int rs = tt - tc[j] * g.R * g.S;
+    trr[j] = rs / g.S;
+    tss[j] = rs - trr[j] * g.S;
+  }
+  float acc[MAXT][8];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+  const int npix = g.B * g.P * g.Q;
+  const int p0 = blockIdx.x * pix_per_block;
+  int p1 = p0 + pix_per_block;
+  if (p1 > npix) p1 = npix;
+  int q = p0 % g.Q, t0 = p0 / g.Q;
+  int p = t0 % g.P, b = t0 / g.P;
+  for (int pix = p0; pix < p1; ++pix) {
+    float d[8];
+    unpack8(reinterpret_cast<const uint4*>(dy)[(size_t)pix * cgn + cg], d);
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int ih = p * g.sh - g.ph + trr[j], iw = q * g.sw - g.pw + tss[j];
+      const bool ok = tv[j] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      const float xv = ok ? x[(((size_t)b * g.H + ih) * g.W + iw) * g.Cin + tc[j]] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(xv, d[e], acc[j][e]);
+    }
+    if (++q == g.Q) { q = 0; if (++p == g.P) { p = 0; ++b; } }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+    if (tv[j]) {
+      const int t = tl + j * ntl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(dw + (size_t)(cg * 8 + e) * g.taps + t, acc[j][e]);
+    }
+}
+
+static inline int stem_block(int K) { return (256 / (K / 8)) * (K / 8); }
+
+extern "C" {
+
+int mpr_stem_fwd_stat_rows(int B, int P, int Q, int K) {
+  const int ppb = stem_block(K) / (K / 8);
+  int grid = ceil_div(B * P * Q, ppb * 8);          // >= 8 pixels per thread
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  return grid;
+}
+
+int mpr_stem_fwd(const float* x, const float* w, void* y, float* partials, int B, int H, int W, int Cin, int K, int R,
+                 int S, int sh, int sw, int ph, int pw, void* stream) {
+  MPR_REQUIRE(x && w && y, "mpr_stem_fwd: null pointer");
+  MPR_REQUIRE(K % 8 == 0 && K / 8 <= 256, "mpr_stem_fwd: K must be a multiple of 8, <= 2048 (got %d)", K);
+  StemGeom g = {B, H, W, Cin, K, R, S, sh, sw, ph, pw, (H + 2 * ph - R) / sh + 1, (W + 2 * pw - S) / sw + 1,
+                Cin * R * S};
+  MPR_REQUIRE(g.P > 0 && g.Q > 0, "mpr_stem_fwd: empty output");
+  MPR_REQUIRE((long long)B * g.P * g.Q * K < (1ll << 31), "mpr_stem_fwd: tensor exceeds 2^31 elements");
+  const size_t smem = sizeof(float) * g.taps * K;
+  MPR_REQUIRE(smem <= 48 * 1024, "mpr_stem_fwd: filter too large for the direct kernel (%zu B)", smem);
+  const int grid = mpr_stem_fwd_stat_rows(B, g.P, g.Q, K);
+  stem_fwd_kernel<<<grid, stem_block(K), smem, (hipStream_t)stream>>>(x, w, (bf16_t*)y, partials, g);
+  MPR_LAUNCH_CHECK("stem_fwd_kernel");
+  return MPR_OK;
+}
+
+int mpr_stem_wgrad(const float* x, const void* dy, float* dw, int accumulate, int B, int H, int W, int Cin, int K,
+                   int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+  MPR_REQUIRE(x && dy && dw, "mpr_stem_wgrad: null pointer");
+  MPR_REQUIRE(K % 8 == 0 && K / 8 <= 256, "mpr_stem_wgrad: K must be a multiple of 8, <= 2048 (got %d)", K);
+  StemGeom g = {B, H, W, Cin, K, R, S, sh, sw, ph, pw, (H + 2 * ph - R) / sh + 1, (W + 2 * pw - S) / sw + 1,
+                Cin * R * S};
+  const int block = stem_block(K), ntl = block / (K / 8);
+  MPR_REQUIRE(g.taps <= ntl * 4, "mpr_stem_wgrad: %d taps do not fit %d tap lanes x 4", g.taps, ntl);
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) MPR_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * g.taps, st));
+  const int npix = B * g.P * g.Q;
+  int grid = 2048;
+  int ppb = ceil_div(npix, grid);
+  if (ppb < 16) ppb = 16;
+  grid = ceil_div(npix, ppb);
+  const int maxt = ceil_div(g.taps, ntl);
+  if (maxt == 1) stem_wgrad_kernel<1><<<grid, block, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb);
+  else if (maxt == 2) stem_wgrad_kernel<2><<<grid, block, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb);
+  else if (maxt == 3) stem_wgrad_kernel<3><<<grid, block, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb);
+  else stem_wgrad_kernel<4><<<grid, block, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb);
+  MPR_LAUNCH_CHECK("stem_wgrad_kernel");
+  return MPR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+"""Image encoder -- drop-in counterpart of /root/reference/src/image_encoder.py:8-29.
+
+The reference delegates the backbone to ``timm.create_model(name, num_classes, pretrained=True,
+in_chans)`` (an un-vendored dependency that FETCHES weights).  Here the backbone is built in-repo,
+random-initialised with timm's ResNet scheme (kaiming-normal fan_out convs, BN weight 1 / bias 0,
+zero-initialised last BN of every residual branch) and keeps timm's ``state_dict`` key names
+(``conv1``, ``bn1``, ``layer{1..4}.{i}.{conv1,bn1,conv2,bn2,downsample.{0,1}}``), so a timm
+checkpoint loads unchanged.  ``pretrained`` is accepted and ignored (there is no network).
+Activations are channels-last bf16 inside; the module boundary is the reference's
+(``image`` fp32 [B, in_chans, H, W] in, fp32 [B, num_features + 2] out).
+"""
+from typing import Dict
+
+import torch
+from torch import Tensor, nn
+
+from .layers import BasicBlock, BatchNormParams, PoolTailFn, StemFn
+from .ops import ConvGeom
+
+_RESNETS = {'resnet10t': None, 'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3), 'resnet14': (1, 2, 2, 1),
+            'resnet10': (1, 1, 1, 1)}
+
+
+class ResNetBackbone(nn.Module):
+    """BasicBlock ResNet (timm/torchvision topology): 7x7/2 conv - BN - ReLU - maxpool 3x3/2 - 4 stages."""
+
+    def __init__(self, blocks=(2, 2, 2, 2), in_chans: int = 1, zero_init_last: bool = True):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_chans, 64, 7, 2, 3, bias=False)
+        self.bn1 = BatchNormParams(64)
+        self.geom = ConvGeom(tuple(self.conv1.weight.shape), 2, 3)
+        cin = 64
+        for li, (reps, ch) in enumerate(zip(blocks, (64, 128, 256, 512)), start=1):
+            stride = 1 if li == 1 else 2
+            seq = [BasicBlock(2, cin, ch, stride, downsample=(stride != 1 or cin != ch))]
+            seq += [BasicBlock(2, ch, ch, 1, downsample=False) for _ in range(1, reps)]
+            setattr(self, f'layer{li}', nn.Sequential(*seq))
+            cin = ch
+        self.num_features = 512
+        self.in_chans = in_chans
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        if zero_init_last:
+            for m in self.modules():
+                if isinstance(m, BasicBlock):
+                    nn.init.zeros_(m.bn2.weight)
+
+    def forward_features(self, image: Tensor) -> Tensor:
+        """fp32 [B, in_chans, H, W] -> channels-last bf16 [B, H/32, W/32, 512]."""
+        B, C, H, W = image.shape
+        x = image.float()
+        x = x.reshape(B, H, W, 1) if C == 1 else x.permute(0, 2, 3, 1)
+        x = x.contiguous()
+        out = StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
+        for li in range(1, 5):
+            for blk in getattr(self, f'layer{li}'):
+                out = blk(out)
+        return out
+
+
+def create_backbone(name: str, in_chans: int = 1):
+    if name in _RESNETS and _RESNETS[name] is not None:
+        return ResNetBackbone(_RESNETS[name], in_chans)
+    raise NotImplementedError(
+        f"image backbone '{name}': only BasicBlock ResNets ({', '.join(k for k, v in _RESNETS.items() if v)}) "
+        f"have native gfx950 kernels so far")
+
+
+class ImageEncoder(nn.Module):
+    """Reference: src/image_encoder.py:8-29 (same arguments, same forward keyword contract)."""
+
+    def __init__(self, name: str, num_classes: int = 0, pretrained: bool = False, dropout: float = 0.1,
+                 in_chans: int = 1, metadata: bool = True) -> None:
+        super().__init__()
+        if num_classes != 0:
+            raise NotImplementedError('ImageEncoder: num_classes must be 0 (feature extractor), as in every card')
+        self.backbone = create_backbone(name, in_chans)
+        self.dim_out = self.backbone.num_features + 2 * metadata
+        self.metadata = metadata
+        self.p_drop = float(dropout)
+
+    def forward(self, image: Tensor, **kwargs) -> Tensor:
+        fmap = self.backbone.forward_features(image)
+        meta = kwargs['image_shape'].contiguous() if self.metadata else None     # (orig H, W) / tensor H  (:26-27)
+        p = self.p_drop if self.training else 0.0
+        return PoolTailFn.apply(fmap, meta, 'avg', image.shape[2], p)

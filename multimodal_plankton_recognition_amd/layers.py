@@ -1,0 +1,250 @@
+"""Fused building blocks of both ResNets (image: 2-D, profile: 1-D) as autograd Functions.
+
+Each Function's forward/backward is a hand-ordered sequence of C-ABI kernel launches
+(``ops.py``); autograd only chains stem -> blocks -> pool/tail -> projection -> loss, so no torch
+arithmetic kernel runs between them (the skip-connection gradient add is fused into the dgrad
+epilogue).  Parameter containers are ordinary ``torch.nn`` modules so that ``state_dict()`` keys,
+shapes and default initialisation match the reference modules
+(src/profile_encoder.py:111-148,151-240; timm ResNet BasicBlock).
+"""
+import random
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import ConvGeom, MASK_NONE, MASK_RECOMPUTE, MASK_Y
+
+_seed_rng = None
+
+
+def next_seed():
+    """Dropout seeds: a Python stream derived from torch's global seed (no device sync)."""
+    global _seed_rng
+    if _seed_rng is None:
+        _seed_rng = random.Random(torch.initial_seed())
+    return _seed_rng.getrandbits(32)
+
+
+class BatchNormParams(nn.Module):
+    """Parameter/buffer container with nn.BatchNorm{1,2}d's state_dict layout and defaults
+    (momentum 0.1, eps 1e-5).  ``num_batches_tracked`` is counted on the host and flushed into the
+    buffer whenever the state_dict is taken (keeps 40 one-element kernels out of every step)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self._pending = 0
+        self._register_state_dict_hook(BatchNormParams._flush_hook)
+
+    @staticmethod
+    def _flush_hook(module, state_dict, prefix, local_metadata):
+        if module._pending:
+            module.num_batches_tracked += module._pending
+            module._pending = 0
+            state_dict[prefix + 'num_batches_tracked'] = module.num_batches_tracked
+
+    def count_batch(self):
+        self._pending += 1
+
+
+def _bn_coefs(stats, count, bn, train, x=None):
+    st = ops.bn_coefs(stats, count, bn, train, x)
+    if train:
+        bn.count_batch()
+    return st
+
+
+def _rows(t):
+    return t.numel() // t.shape[-1]
+
+
+# ================================================================================================ stem
+class StemFn(torch.autograd.Function):
+    """conv(k, stride 2, few input channels) -> BN -> ReLU -> MaxPool(3, 2, 1), one Function.
+    timm ResNet conv1/bn1/act1/maxpool; ProfileCNN.forward_features src/profile_encoder.py:215-220."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, bn_w, bn_b, mod):
+        g = mod.geom
+        train = mod.training
+        y, stats = ops.stem_fwd(x, conv_w, g, train)
+        st = _bn_coefs(stats, _rows(y), mod.bn1, train)
+        pooled, idx = ops.bn_relu_maxpool_fwd(y, st)
+        if train:
+            ctx.save_for_backward(x, y, idx, conv_w, bn_w)
+            ctx.st, ctx.g = st, g
+        ctx.train = train
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        if not ctx.train:
+            raise RuntimeError('backward through an eval-mode BatchNorm stem is not implemented')
+        x, y, idx, conv_w, bn_w = ctx.saved_tensors
+        da = ops.maxpool_bwd(dpooled.contiguous(), idx, y.shape)
+        dx, dgamma, dbeta, _ = ops.bn_bwd(da, None, y, bn_w, ctx.st, MASK_RECOMPUTE)
+        dw = ops.stem_wgrad(x, dx, ctx.g, conv_w.shape)
+        return None, dw, dgamma, dbeta, None
+
+
+# ================================================================================================ basic block
+class BasicBlockFn(torch.autograd.Function):
+    """conv3-BN-ReLU-conv3-BN (+ 1x1-conv-BN shortcut) + add + ReLU.
+    src/profile_encoder.py:132-148 (1-D) and timm BasicBlock (2-D) -- same kernels, H == 1 for 1-D."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, mod):
+        train = mod.training
+        c1, c2, cd = mod.geom1, mod.geom2, mod.geomd
+        need_bwd = train
+        wf1, wd1 = ops.packed_weights(w1, c1, need_bwd)
+        wf2, wd2 = ops.packed_weights(w2, c2, need_bwd)
+        x1, s1 = ops.conv_fwd(x, wf1, c1, train)
+        st1 = _bn_coefs(s1, _rows(x1), mod.bn1, train, x1)
+        a1 = ops.bn_apply(x1, st1, None, True)
+        x2, s2 = ops.conv_fwd(a1, wf2, c2, train)
+        st2 = _bn_coefs(s2, _rows(x2), mod.bn2, train, x2)
+        if wd is not None:
+            wfd, wdd = ops.packed_weights(wd, cd, need_bwd)
+            xd, sd = ops.conv_fwd(x, wfd, cd, train)
+            std = _bn_coefs(sd, _rows(xd), mod.downsample[1], train, xd)
+            identity = ops.bn_apply(xd, std, None, False)
+        else:
+            xd = std = wdd = None
+            identity = x
+        out = ops.bn_apply(x2, st2, identity, True)
+        ctx.train = train
+        if train:
+            ctx.save_for_backward(x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd)
+            ctx.misc = (st1, st2, std, c1, c2, cd, wd1, wd2, wdd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.train:
+            raise RuntimeError('backward through an eval-mode BatchNorm block is not implemented')
+        x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd = ctx.saved_tensors
+        st1, st2, std, c1, c2, cd, wd1, wd2, wdd = ctx.misc
+        dout = dout.contiguous()
+        # out = relu(bn2(x2) + identity):  dz = dout * (out > 0) feeds bn2 AND the shortcut
+        dx2, dg2, db2, dz = ops.bn_bwd(dout, out, x2, g2, st2, MASK_Y, want_dz=True)
+        dw2 = ops.conv_wgrad(a1, dx2, c2, w2.shape)
+        da1 = ops.conv_dgrad(dx2, wd2, c2, a1.shape)
+        dx1, dg1, db1, _ = ops.bn_bwd(da1, a1, x1, g1, st1, MASK_Y)
+        dw1 = ops.conv_wgrad(x, dx1, c1, w1.shape)
+        if wd is not None:
+            dxd, dgd, dbd, _ = ops.bn_bwd(dz, None, xd, gd, std, MASK_NONE)
+            dwd = ops.conv_wgrad(x, dxd, cd, wd.shape)
+            skip = ops.conv_dgrad(dxd, wdd, cd, x.shape)
+        else:
+            dgd = dbd = dwd = None
+            skip = dz
+        dx = ops.conv_dgrad(dx1, wd1, c1, x.shape, add=skip)      # skip-connection gradient fused in the epilogue
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, dims, in_channels, out_channels, stride, downsample):
+        super().__init__()
+        conv = nn.Conv2d if dims == 2 else nn.Conv1d
+        self.conv1 = conv(in_channels, out_channels, 3, stride, 1, bias=False)
+        self.bn1 = BatchNormParams(out_channels)
+        self.conv2 = conv(out_channels, out_channels, 3, 1, 1, bias=False)
+        self.bn2 = BatchNormParams(out_channels)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(conv(in_channels, out_channels, 1, stride, 0, bias=False),
+                                            BatchNormParams(out_channels))
+        self.stride = stride
+        self.geom1 = ConvGeom(tuple(self.conv1.weight.shape), stride, 1)
+        self.geom2 = ConvGeom(tuple(self.conv2.weight.shape), 1, 1)
+        self.geomd = ConvGeom(tuple(self.downsample[0].weight.shape), stride, 0) if downsample else None
+
+    def forward(self, x):
+        ds = self.downsample
+        return BasicBlockFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
+                                  self.bn2.weight, self.bn2.bias,
+                                  ds[0].weight if ds is not None else None,
+                                  ds[1].weight if ds is not None else None,
+                                  ds[1].bias if ds is not None else None, self)
+
+
+# ================================================================================================ pool + tail
+class PoolTailFn(torch.autograd.Function):
+    """global pool (avg | max) -> concat(metadata / denom) -> dropout.
+    src/image_encoder.py:24-29 (timm global avg pool) and src/profile_encoder.py:232-240."""
+
+    @staticmethod
+    def forward(ctx, fmap, meta, mode, denom, p_drop):
+        feat, idx = ops.global_pool_fwd(fmap, mode)
+        out, mask = ops.tail_fwd(feat, meta, denom, p_drop, next_seed() if p_drop > 0 else 0)
+        ctx.save_for_backward(idx, mask)
+        ctx.cfg = (mode, p_drop, feat.shape[1], fmap.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, mask = ctx.saved_tensors
+        mode, p_drop, Fd, shape = ctx.cfg
+        dfeat = ops.tail_bwd(dout.contiguous(), mask, p_drop, Fd)
+        return ops.global_pool_bwd(dfeat, idx, shape, mode), None, None, None, None
+
+
+class TailFn(torch.autograd.Function):
+    """concat(metadata / denom) -> dropout on already-pooled fp32 features (transformer / LSTM encoders)."""
+
+    @staticmethod
+    def forward(ctx, feat, meta, denom, p_drop):
+        out, mask = ops.tail_fwd(feat.contiguous(), meta, denom, p_drop, next_seed() if p_drop > 0 else 0)
+        ctx.save_for_backward(mask)
+        ctx.cfg = (p_drop, feat.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mask,) = ctx.saved_tensors
+        p_drop, Fd = ctx.cfg
+        return ops.tail_bwd(dout.contiguous(), mask, p_drop, Fd), None, None, None
+
+
+# ================================================================================================ linear (exact fp32)
+_ones_cache = {}
+
+
+def _ones(n, device):
+    key = (n, str(device))
+    if key not in _ones_cache:
+        _ones_cache[key] = torch.ones(n, 1, dtype=torch.float32, device=device)
+    return _ones_cache[key]
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) on the exact-fp32 MFMA GEMM.  nn.Linear at src/model.py:31-32,40-41,164,316."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.gemm(x, weight, trans_b=True, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.gemm(dy, weight) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm(dy, x, trans_a=True)
+        db = ops.gemm(_ones(dy.shape[0], dy.device), dy, trans_a=True).reshape(-1) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias)

@@ -1,0 +1,333 @@
+"""Thin tensor-level wrappers over the C-ABI kernels (libmpr_hip.so).
+
+Everything here takes / returns device tensors and enqueues work on torch's current HIP stream.
+Feature maps are channels-last bf16: ``[B, H, W, C]`` (2-D) or ``[B, L, C]`` (1-D == H of 1).
+PyTorch supplies memory (caching allocator) and streams only -- no torch arithmetic runs here.
+"""
+import torch
+
+from . import _native as N
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _geom(x):
+    """[B,L,C] | [B,H,W,C] -> (B, H, W, C)."""
+    if x.dim() == 3:
+        return x.shape[0], 1, x.shape[1], x.shape[2]
+    return tuple(x.shape)
+
+
+def _like_spatial(x, B, P, Q, K):
+    return (B, Q, K) if x.dim() == 3 else (B, P, Q, K)
+
+
+class ConvGeom:
+    """Static description of one convolution (torch OIHW / OIW weight)."""
+
+    def __init__(self, weight_shape, stride, pad):
+        if len(weight_shape) == 3:       # Conv1d [K, C, S]
+            self.K, self.C, self.S = weight_shape
+            self.R, self.sh, self.sw, self.ph, self.pw = 1, 1, stride, 0, pad
+        else:
+            self.K, self.C, self.R, self.S = weight_shape
+            self.sh = self.sw = stride
+            self.ph = self.pw = pad
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.ph - self.R) // self.sh + 1, (W + 2 * self.pw - self.S) // self.sw + 1
+
+    @property
+    def tail(self):
+        return (self.R, self.S, self.sh, self.sw, self.ph, self.pw)
+
+
+# ------------------------------------------------------------------------------------------ weights
+_pack_cache = {}
+
+
+def packed_weights(weight, geom, need_dgrad=True):
+    """bf16 GEMM panels of an fp32 OIHW weight, cached on (storage, version)."""
+    key = (weight.data_ptr(), weight._version, need_dgrad)
+    hit = _pack_cache.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    nf = (geom.K + 127) // 128 * 128 * ((geom.R * geom.S * geom.C + 63) // 64 * 64)
+    nd = (geom.C + 127) // 128 * 128 * ((geom.R * geom.S * geom.K + 63) // 64 * 64)
+    wf = torch.empty(nf, dtype=BF16, device=weight.device)
+    wd = torch.empty(nd, dtype=BF16, device=weight.device) if need_dgrad else None
+    N.call('mpr_conv_pack_weights', weight.detach(), wf, wd, geom.K, geom.C, geom.R, geom.S)
+    _pack_cache[id(weight)] = (key, wf, wd)
+    return wf, wd
+
+
+# ------------------------------------------------------------------------------------------ conv
+def conv_fwd(x, wf, g, want_stats):
+    B, H, W, C = _geom(x)
+    assert C == g.C, f'conv_fwd: input has {C} channels, weight expects {g.C}'
+    P, Q = g.out_hw(H, W)
+    y = torch.empty(_like_spatial(x, B, P, Q, g.K), dtype=BF16, device=x.device)
+    stats = None
+    if want_stats:
+        rows = N.query('mpr_conv_fwd_stat_rows', B, P, Q, g.K)
+        stats = torch.empty(rows, 2, g.K, dtype=F32, device=x.device)
+    N.call('mpr_conv_fwd', x, wf, y, stats, B, H, W, C, g.K, *g.tail)
+    return y, stats
+
+
+def conv_dgrad(dy, wd, g, x_shape, add=None):
+    dx = torch.empty(x_shape, dtype=BF16, device=dy.device)
+    B, H, W, C = _geom(dx)
+    N.call('mpr_conv_dgrad', dy, wd, dx, add, B, H, W, C, g.K, *g.tail)
+    return dx
+
+
+def conv_wgrad(x, dy, g, weight_shape):
+    B, H, W, C = _geom(x)
+    ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
+    dw = torch.empty(weight_shape, dtype=F32, device=x.device)
+    N.call('mpr_conv_wgrad', x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail)
+    return dw
+
+
+def stem_fwd(x, weight, g, want_stats):
+    """x: fp32 [B,H,W,Cin] / [B,L,Cin] (Cin == 1 may also come as NCHW [B,1,H,W])."""
+    B, H, W, C = _geom(x)
+    P, Q = g.out_hw(H, W)
+    y = torch.empty(_like_spatial(x, B, P, Q, g.K), dtype=BF16, device=x.device)
+    stats = None
+    if want_stats:
+        rows = N.query('mpr_stem_fwd_stat_rows', B, P, Q, g.K)
+        stats = torch.empty(rows, 2, g.K, dtype=F32, device=x.device)
+    N.call('mpr_stem_fwd', x, weight.detach(), y, stats, B, H, W, C, g.K, *g.tail)
+    return y, stats
+
+
+def stem_wgrad(x, dy, g, weight_shape):
+    B, H, W, C = _geom(x)
+    dw = torch.empty(weight_shape, dtype=F32, device=x.device)
+    N.call('mpr_stem_wgrad', x, dy, dw, 0, B, H, W, C, g.K, *g.tail)
+    return dw
+
+
+# ------------------------------------------------------------------------------------------ batch norm
+class BNState:
+    """Per-call BatchNorm coefficients: scale/shift always, mean/invstd in train mode."""
+    __slots__ = ('scale', 'shift', 'mean', 'invstd')
+
+
+def bn_coefs(stats, count, bn, train, x=None):
+    """bn: object with weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps."""
+    C = bn.weight.shape[0]
+    dev = bn.weight.device
+    st = BNState()
+    st.scale = torch.empty(C, dtype=F32, device=dev)
+    st.shift = torch.empty(C, dtype=F32, device=dev)
+    if train:
+        if stats is None:
+            rows = x.numel() // C
+            stats = torch.empty(N.query('mpr_bn_reduce_rows', rows, C), 2, C, dtype=F32, device=dev)
+            N.call('mpr_bn_stats', x, stats, rows, C)
+        st.mean = torch.empty(C, dtype=F32, device=dev)
+        st.invstd = torch.empty(C, dtype=F32, device=dev)
+        N.call('mpr_bn_finalize_stats', stats, stats.shape[0], count, bn.weight.detach(), bn.bias.detach(),
+               bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps), st.scale, st.shift,
+               st.mean, st.invstd, C)
+    else:
+        st.mean = st.invstd = None
+        N.call('mpr_bn_eval_coefs', bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+               float(bn.eps), st.scale, st.shift, C)
+    return st
+
+
+def bn_apply(x, st, residual=None, relu=True):
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    N.call('mpr_bn_apply', x, st.scale, st.shift, residual, int(relu), y, x.numel() // C, C)
+    return y
+
+
+MASK_NONE, MASK_Y, MASK_RECOMPUTE = 0, 1, 2
+
+
+def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False):
+    """-> dx (bf16), dgamma, dbeta (fp32), dz (bf16 | None)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dev = x.device
+    parts = torch.empty(N.query('mpr_bn_reduce_rows', rows, C), 2, C, dtype=F32, device=dev)
+    N.call('mpr_bn_bwd_reduce', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, rows, C)
+    dgamma = torch.empty(C, dtype=F32, device=dev)
+    dbeta = torch.empty(C, dtype=F32, device=dev)
+    coef = torch.empty(3, C, dtype=F32, device=dev)
+    N.call('mpr_bn_bwd_finalize', parts, parts.shape[0], rows, gamma.detach(), st.mean, st.invstd, dgamma, dbeta, 0,
+           coef, C)
+    dx = torch.empty_like(x)
+    dz = torch.empty_like(x) if want_dz else None
+    N.call('mpr_bn_bwd_apply', dy, y, x, coef, st.scale, st.shift, mask_mode, dx, dz, rows, C)
+    return dx, dgamma, dbeta, dz
+
+
+# ------------------------------------------------------------------------------------------ pooling
+def _pool_geom(x, k, s, p):
+    B, H, W, C = _geom(x)
+    if x.dim() == 3:
+        return B, H, W, C, 1, k, 1, s, 0, p
+    return B, H, W, C, k, k, s, s, p, p
+
+
+def bn_relu_maxpool_fwd(x, st, k=3, s=2, p=1):
+    B, H, W, C, RH, RW, SH, SW, PH, PW = _pool_geom(x, k, s, p)
+    P, Q = (H + 2 * PH - RH) // SH + 1, (W + 2 * PW - RW) // SW + 1
+    y = torch.empty(_like_spatial(x, B, P, Q, C), dtype=BF16, device=x.device)
+    idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+    N.call('mpr_bn_relu_maxpool_fwd', x, st.scale if st is not None else None,
+           st.shift if st is not None else None, y, idx, B, H, W, C, RH, RW, SH, SW, PH, PW)
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, x_shape, k=3, s=2, p=1):
+    dx = torch.empty(x_shape, dtype=BF16, device=dy.device)
+    B, H, W, C, RH, RW, SH, SW, PH, PW = _pool_geom(dx, k, s, p)
+    N.call('mpr_maxpool_bwd', dy, idx, dx, B, H, W, C, RH, RW, SH, SW, PH, PW)
+    return dx
+
+
+def global_pool_fwd(x, mode):
+    B, C = x.shape[0], x.shape[-1]
+    L = x.numel() // (B * C)
+    y = torch.empty(B, C, dtype=F32, device=x.device)
+    if mode == 'avg':
+        N.call('mpr_global_avgpool_fwd', x, y, B, L, C)
+        return y, None
+    idx = torch.empty(B, C, dtype=torch.int32, device=x.device)
+    N.call('mpr_global_maxpool_fwd', x, y, idx, B, L, C)
+    return y, idx
+
+
+def global_pool_bwd(dy, idx, x_shape, mode):
+    dx = torch.empty(x_shape, dtype=BF16, device=dy.device)
+    B, C = x_shape[0], x_shape[-1]
+    L = dx.numel() // (B * C)
+    if mode == 'avg':
+        N.call('mpr_global_avgpool_bwd', dy, dx, B, L, C)
+    else:
+        N.call('mpr_global_maxpool_bwd', dy, idx, dx, B, L, C)
+    return dx
+
+
+# ------------------------------------------------------------------------------------------ fp32 GEMM & friends
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, alpha=1.0, beta=0.0):
+    """op(a) @ op(b) for 2-D (or batched 3-D, same batch) fp32 row-major tensors."""
+    batched = a.dim() == 3
+    if batched:
+        nb = a.shape[0]
+        a2, b2 = a.shape[1:], b.shape[1:]
+    else:
+        nb, a2, b2 = 1, a.shape, b.shape
+    M, K = (a2[1], a2[0]) if trans_a else (a2[0], a2[1])
+    Kb, Nn = (b2[1], b2[0]) if trans_b else (b2[0], b2[1])
+    assert K == Kb, f'gemm: inner dimensions differ ({K} vs {Kb})'
+    if out is None:
+        out = torch.empty((nb, M, Nn) if batched else (M, Nn), dtype=F32, device=a.device)
+    N.call('mpr_gemm_f32', a, b, out, bias, M, Nn, K, a2[1], b2[1], Nn, int(trans_a), int(trans_b), float(alpha),
+           float(beta), nb, a2[0] * a2[1], b2[0] * b2[1], M * Nn)
+    return out
+
+
+def tail_fwd(feat, meta, denom, p_drop, seed):
+    B, Fd = feat.shape
+    Mm = 0 if meta is None else meta.shape[1]
+    out = torch.empty(B, Fd + Mm, dtype=F32, device=feat.device)
+    mask = torch.empty(B, Fd + Mm, dtype=torch.uint8, device=feat.device) if p_drop > 0 else None
+    N.call('mpr_tail_fwd', feat, meta, 1.0 / float(denom), float(p_drop), int(seed) & 0xffffffff, out, mask, B, Fd, Mm)
+    return out, mask
+
+
+def tail_bwd(dout, mask, p_drop, Fd):
+    B, Wd = dout.shape
+    dfeat = torch.empty(B, Fd, dtype=F32, device=dout.device)
+    N.call('mpr_tail_bwd', dout, mask, float(p_drop), dfeat, B, Fd, Wd - Fd)
+    return dfeat
+
+
+def softmax_ce(logits, labels=None, want_grad=False):
+    rows, C = logits.shape
+    dev = logits.device
+    argmax = torch.empty(rows, dtype=torch.int64, device=dev)
+    if labels is None:
+        N.call('mpr_softmax_ce', logits, None, None, None, argmax, None, rows, C)
+        return None, argmax, None
+    row_loss = torch.empty(rows, dtype=F32, device=dev)
+    loss = torch.empty((), dtype=F32, device=dev)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    N.call('mpr_softmax_ce', logits, labels, row_loss, loss, argmax, dlogits, rows, C)
+    return loss, argmax, dlogits
+
+
+def scale_by_scalar(x, s):
+    y = torch.empty_like(x)
+    N.call('mpr_scale_by_scalar', x, s, y, x.numel())
+    return y
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+class FusedSGD:
+    """torch.optim.SGD semantics (src/model.py:147-148) as ONE multi-tensor launch per step."""
+
+    def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.momentum, self.dampening = float(lr), float(momentum), float(dampening)
+        self.weight_decay, self.nesterov = float(weight_decay), bool(nesterov)
+        self.bufs = {}
+        self.steps = 0
+        self._table_key = None
+        self._table = None
+        self._grads = None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def _build_table(self, live):
+        rows = []
+        for p in live:
+            if id(p) not in self.bufs:
+                self.bufs[id(p)] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            rows.append([p.data_ptr(), p.grad.data_ptr(), self.bufs[id(p)].data_ptr(), p.numel()])
+        return torch.tensor(rows, dtype=torch.int64).pin_memory().to(live[0].device, non_blocking=True)
+
+    @torch.no_grad()
+    def step(self):
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            return
+        for p in live:
+            if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == F32 and p.grad.dtype == F32):
+                raise N.NativeLibraryError('FusedSGD needs contiguous fp32 parameters and gradients')
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
+        if key != self._table_key:
+            first_for = [id(p) not in self.bufs for p in live]
+            if any(first_for) and not all(first_for) and self.momentum:
+                # a parameter joined later: give it torch's "first step" (buf = g) by a solo launch below
+                raise N.NativeLibraryError('FusedSGD: parameter set changed after the first step')
+            self._table = self._build_table(live)
+            self._table_key = key
+        first = 1 if self.steps == 0 else 0
+        N.call('mpr_sgd_multi', self._table, len(live), max(p.numel() for p in live), self.lr, self.momentum,
+               self.dampening, self.weight_decay, int(self.nesterov), first)
+        self.steps += 1
+        # parameters were mutated through raw pointers: bump their version counters so that cached
+        # bf16 weight panels (packed_weights) are rebuilt
+        FusedSGD._bump_versions(live)
+
+    @staticmethod
+    def _bump_versions(params):
+        for p in params:
+            torch.autograd.graph.increment_version(p)
+
+    def state_dict(self):
+        return {'steps': self.steps, 'momentum_buffers': [self.bufs.get(id(p)) for p in self.params],
+                'hyper': dict(lr=self.lr, momentum=self.momentum, dampening=self.dampening,
+                              weight_decay=self.weight_decay, nesterov=self.nesterov)}

@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/mpr_hip.h declares; calling a
+kernel wrapper with CPU tensors fails loudly (there is no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from multimodal_plankton_recognition_amd import _native
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_native.LIB_PATH), 'run __graft_entry__.build() first'
+    names = _native.exported_symbols()
+    text = open(_native.HEADER_PATH).read()
+    declared = set(re.findall(r'\b(mpr_\w+)\s*\(', re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)))
+    assert declared and declared == set(names)
+    assert _native.query('mpr_abi_version') == 1
+    assert _native.lib().mpr_target_arch() == b'gfx950'
+
+
+def test_size_queries_match_documented_tiling():
+    assert _native.query('mpr_conv_fwd_stat_rows', 512, 56, 56, 64) == 512 * 56 * 56 // 256
+    assert _native.query('mpr_conv_fwd_stat_rows', 512, 28, 28, 128) == 512 * 28 * 28 // 128
+    assert _native.query('mpr_loss_workspace_floats') >= 1024
+
+
+def test_no_cpu_fallback():
+    from multimodal_plankton_recognition_amd import ops
+    with pytest.raises(_native.NativeLibraryError):
+        ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+    from multimodal_plankton_recognition_amd.coordination import CLIPLoss
+    with pytest.raises(_native.NativeLibraryError):
+        CLIPLoss()(torch.randn(4, 8), torch.randn(4, 8), 1)
+
+
+def test_modules_keep_reference_state_dict_keys(golden):
+    from multimodal_plankton_recognition_amd.profile_encoder import ProfileCNN
+    from multimodal_plankton_recognition_amd.model import MultiModel
+    g = golden('profile_cnn_b8_2222')
+    m = ProfileCNN(dim_in=6, blocks=[2, 2, 2, 2], base_channels=8)
+    assert sorted(m.state_dict()) == sorted(k[3:] for k in g if k.startswith('sd.'))
+    mm = MultiModel(dim_embed=32, image_encoder_args=dict(name='resnet18'),
+                    profile_encoder_args=dict(dim_in=6, blocks=[1, 1, 1, 1], base_channels=8),
+                    coordination_args=dict(method='siglipplus'), optim_args=dict(lr=1e-3))
+    keys = set(mm.state_dict())
+    for k in ('image_encoder.backbone.conv1.weight', 'image_encoder.backbone.layer2.0.downsample.1.running_var',
+              'image_projection.weight', 'profile_encoder.layer4.0.downsample.0.weight', 'profile_projection.weight',
+              'loss.siglip.logit_scale', 'loss.siglip.bias'):
+        assert k in keys, k
+    assert mm.image_projection.weight.shape == (32, 514) and mm.profile_projection.weight.shape == (32, 65)
+    with pytest.raises(Exception, match='Coordination loss not found'):
+        MultiModel(dim_embed=32, image_encoder_args=dict(name='resnet18'),
+                   profile_encoder_args=dict(dim_in=6, blocks=[1, 1, 1, 1], base_channels=8),
+                   coordination_args=dict(method='nope'), optim_args=dict(lr=1e-3))
