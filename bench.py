@@ -1,0 +1,172 @@
+"""Headline benchmark: samples/s (image+profile pairs) of one full train_multi optimisation step
+(forward + backward + SGD) on BASELINE config C3 -- ResNet-18 (1-channel 224x224) + ProfileCNN[2,2,2,2]
++ CLIP loss, D = 512, batch 512 per GPU, synthetic on-device data, random-init weights.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with hipEvent pairs around every launch of
+the dominant kernel (conv_igemm_kernel, forward + dgrad instantiations) inside the timed region;
+`cpu_baseline` times the CPU oracle (plain-torch fp32 restatement of the same step) on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CARD = os.path.join(ROOT, 'model_cards', 'resnet18_cnn_2_512_clip.yaml')
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def synthetic_batch(B, T, device, seed):
+    """image ~ clamp(N(0.6136, 0.0938), 0, 1)*2-1, profile ~ U[-1, 1]."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    image = (torch.randn(B, 1, T, T, generator=g, device=device) * 0.0938 + 0.6136).clamp_(0, 1) * 2 - 1
+    profile = torch.rand(B, T, 6, generator=g, device=device) * 2 - 1
+    image_shape = torch.randint(32, 401, (B, 2), generator=g, device=device)
+    profile_len = torch.randint(8, 1025, (B, 1), generator=g, device=device)
+    return {'image': image, 'profile': profile, 'image_shape': image_shape, 'profile_len': profile_len}
+
+
+def cpu_baseline(card, T, threads):
+    """Oracle (CPU restatement) timed on a bounded sample of the same workload: batch 32 instead of 512."""
+    from oracle import model as OM
+    from multimodal_plankton_recognition_amd.model import MultiModel
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    Bc = 32
+    model = MultiModel(card['dim_embedding'], card['image_encoder_args'], card['profile_encoder_args'],
+                       card['coordination_args'], card['optim_args'])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
+    cfg = {k: card[k] for k in ('image_encoder_args', 'profile_encoder_args', 'coordination_args', 'optim_args')}
+    batch = synthetic_batch(Bc, T, 'cpu', 1234)
+    batch['buckets'] = 1
+    bufs = {}
+    OM.train_step(sd, batch, cfg, bufs)                       # warm-up
+    times = []
+    t_end = time.time() + 25.0
+    while len(times) < 5 and (time.time() < t_end or not times):
+        t0 = time.time()
+        OM.train_step(sd, batch, cfg, bufs)
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': round(Bc / med, 2), 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle (torch fp32 CPU) full step at batch {Bc} (bounded sample of the batch-512 workload), '
+                      f'median of {len(times)} steps, dropout off'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the card: 512)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from multimodal_plankton_recognition_amd import _native as N
+    from multimodal_plankton_recognition_amd.model import MultiModel
+    from multimodal_plankton_recognition_amd import distributed as D
+
+    card = yaml.safe_load(open(CARD))
+    T = card['target_size']
+    B = args.batch or card['bs']
+    if world > 1:
+        D.init(dev)
+
+    torch.manual_seed(0)                                      # identical init on every rank
+    model = MultiModel(card['dim_embedding'], card['image_encoder_args'], card['profile_encoder_args'],
+                       card['coordination_args'], card['optim_args']).to(dev).train()
+    opt = model.configure_optimizers()
+    stepper = D.DataParallelStep(model, opt, world) if world > 1 else None
+    batch = synthetic_batch(B, T, dev, 1234 + rank)
+    batch['buckets'] = card['buckets']
+
+    def one_step():
+        if stepper is not None:
+            return stepper.step(batch)
+        opt.zero_grad()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        one_step()
+    model.train_loss.clear()
+
+    lib = N.lib()
+    lib.mpr_prof_reset()
+    lib.mpr_prof_enable(1)
+    if world > 1:
+        D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        D.barrier()
+    elapsed = time.perf_counter() - t0
+    lib.mpr_prof_enable(0)
+    if world > 1:
+        elapsed = D.max_over_ranks(elapsed)
+    loss_val = float(loss)
+
+    def collect(kind):
+        ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        lib.mpr_prof_collect(kind, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
+        return ms.value, work.value, n.value
+
+    if rank == 0:
+        ms_f, w_f, n_f = collect(0)
+        ms_d, w_d, n_d = collect(1)
+        ms_w, w_w, n_w = collect(2)
+        ig_ms, ig_w, ig_n = ms_f + ms_d, w_f + w_d, n_f + n_d
+        achieved = ig_w / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            'metric': 'samples/sec (image+profile pairs) for train_multi', 'value': round(B * world * args.steps / elapsed, 1),
+            'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'C3: model_cards/resnet18_cnn_2_512_clip.yaml -- ResNet-18 (1x224x224) + ProfileCNN[2,2,2,2] '
+                                   '+ CLIP, D=512, full step (fwd+bwd+SGD nesterov), dropout 0.1',
+                       'per_gpu_batch': B, 'global_batch': B * world,
+                       'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'loss': round(loss_val, 5)},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (fwd + dgrad instantiations)',
+                         'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                         'launches': ig_n, 'avg_launch_us': round(ig_ms * 1e3 / max(ig_n, 1), 2),
+                         'share_of_step_time': round(ig_ms / args.steps / ms_per_step, 3),
+                         'wgrad_kernel': {'achieved': round(w_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
+                                          'launches': n_w, 'share_of_step_time': round(ms_w / args.steps / ms_per_step, 3)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            out['cpu_baseline'] = cpu_baseline(card, T, threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        D.shutdown()
+
+
+if __name__ == '__main__':
+    main()

@@ -28,6 +28,11 @@ const char* mpr_target_arch(void);                 /* "gfx950" */
 const char* mpr_last_error(void);
 void mpr_set_error(const char* fmt, ...);
 int mpr_device_check(char* name, int name_len);    /* 0 iff device 0 is gfx950; name: HOST buffer */
+/* opt-in hipEvent profiler around the conv kernels (kinds: 0 igemm fwd, 1 igemm dgrad, 2 wgrad);
+ * collect sums elapsed ms / algorithmic FLOPs / launches into HOST variables (kind -1: all). */
+int mpr_prof_enable(int on);
+int mpr_prof_reset(void);
+int mpr_prof_collect(int kind, double* total_ms, double* total_work, int* launches);
 
 /* ---- convolution as implicit GEMM (bf16 MFMA, fp32 accumulate) ------------------------------
  * Stand in for nn.Conv2d inside timm's ResNet (src/image_encoder.py:24) and nn.Conv1d in
@@ -102,6 +107,14 @@ int mpr_clip_fwd(const float* S, const float* logit_scale, float* row_lse, float
                  int buckets, int n, void* stream);
 int mpr_clip_bwd(float* S, const float* logit_scale, const float* row_lse, const float* col_lse, const float* gout,
                  float* d_logit_scale, float* workspace, int buckets, int n, void* stream);
+/* data-parallel row block of the CLIP loss (the path's one exchange step: the embeddings and two LSE
+ * vectors are all-gathered over RCCL by the caller; extension of src/coordination.py:26-47 to a batch
+ * sharded over ranks): S_blk [rows][ncols], positives at column diag_off + i */
+int mpr_clip_block_fwd(const float* S, const float* logit_scale, float* row_lse, float* diag, float* sum_out,
+                       float* workspace, int rows, int ncols, int diag_off, void* stream);
+int mpr_clip_block_bwd(float* S, const float* logit_scale, const float* lse_own, const float* lse_other,
+                       const float* gout /* [1] or NULL */, float coef, float* d_logit_scale_part, float* workspace,
+                       int rows, int ncols, int diag_off, void* stream);
 int mpr_siglip_fwd(const float* S, const float* logit_scale, const float* bias, float* loss, float* workspace,
                    int buckets, int n, void* stream);
 int mpr_siglip_bwd(float* S, const float* logit_scale, const float* bias, const float* gout, float* d_logit_scale,

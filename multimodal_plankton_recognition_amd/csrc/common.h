@@ -17,6 +17,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define MPR_EHIP 2
 
 extern "C" void mpr_set_error(const char* fmt, ...);
+extern "C" void* mpr_prof_begin(int kind, double work, void* stream);   // no-ops unless mpr_prof_enable(1)
+extern "C" void mpr_prof_end(void* token, void* stream);
 
 #define MPR_REQUIRE(cond, ...)                  \
   do {                                          \

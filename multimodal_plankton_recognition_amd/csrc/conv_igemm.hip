@@ -298,9 +298,11 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
     }                                                                                                 \
     conv_igemm_kernel<WM_, WN_, DG_><<<grid, 256, smem, st>>>(p);                                     \
   } while (0)
+  void* tok = mpr_prof_begin(dgrad ? 1 : 0, 2.0 * (double)p.M * (double)p.Nout * (double)p.Kg, st);
   if (narrow) { if (dgrad) MPR_IGEMM(4, 1, true); else MPR_IGEMM(4, 1, false); }
   else        { if (dgrad) MPR_IGEMM(2, 2, true); else MPR_IGEMM(2, 2, false); }
 #undef MPR_IGEMM
+  mpr_prof_end(tok, st);
   MPR_LAUNCH_CHECK("conv_igemm_kernel");
   return MPR_OK;
 }

@@ -218,12 +218,14 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   nsplit = ceil_div(total_chunks, p.cps);
   dim3 grid(tiles * nsplit);
 #define MPR_WG(WM_, WN_) conv_wgrad_kernel<WM_, WN_><<<grid, 64 * WM_ * WN_, 0, st>>>(p)
+  void* tok = mpr_prof_begin(2, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
   if (WM == 1 && WN == 1) MPR_WG(1, 1);
   else if (WM == 1 && WN == 2) MPR_WG(1, 2);
   else if (WM == 1 && WN == 3) MPR_WG(1, 3);
   else if (WM == 2 && WN == 1) MPR_WG(2, 1);
   else if (WM == 2 && WN == 2) MPR_WG(2, 2);
   else MPR_WG(2, 3);
+  mpr_prof_end(tok, st);
 #undef MPR_WG
   MPR_LAUNCH_CHECK("conv_wgrad_kernel");
   const int total = K * C * R * S;

@@ -135,6 +135,58 @@ __global__ __launch_bounds__(256) void clip_grad_kernel(float* __restrict__ S, c
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ------------------------------------------------------------------------------------------------ CLIP, row block
+// Data-parallel form: a rank owns `rows` samples of one modality and holds S_blk = X_loc * Y_all^T
+// [rows][ncols]; its positives sit at column diag_off + i.  Row LSEs are local; the softmax over the
+// other axis needs the other ranks' LSE vector (all-gathered by the caller).
+__global__ __launch_bounds__(256) void clip_block_row_lse_kernel(const float* __restrict__ S,
+                                                                 const float* __restrict__ ls,
+                                                                 float* __restrict__ row_lse, float* __restrict__ diag,
+                                                                 int rows, int ncols, int diag_off) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float scale = expf(ls[0]);
+  const float* s = S + (size_t)row * ncols;
+  float m = -INFINITY, acc = 0.f;
+  for (int j = lane; j < ncols; j += 64) {
+    const float l = s[j] * scale;
+    if (l > m) { acc = acc * expf(m - l) + 1.f; m = l; } else acc += expf(l - m);
+  }
+  const float gm = wave_max(m);
+  acc = wave_sum(acc * expf(m - gm));
+  if (lane == 0) {
+    row_lse[row] = gm + logf(acc);
+    diag[row] = s[diag_off + row] * scale;
+  }
+}
+
+// S_blk <- coef * (exp(l - lse_own[i]) + exp(l - lse_other[j]) - 2 [j == diag_off + i]) * scale, in place;
+// part[grid] = partial sums of G * l (d logit_scale)
+__global__ __launch_bounds__(256) void clip_block_grad_kernel(float* __restrict__ S, const float* __restrict__ ls,
+                                                              const float* __restrict__ lse_own,
+                                                              const float* __restrict__ lse_other,
+                                                              float* __restrict__ part, int rows, int ncols,
+                                                              int diag_off, float coef) {
+  __shared__ float red[4];
+  const float scale = expf(ls[0]);
+  const long long total = (long long)rows * ncols;
+  float dls = 0.f;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const unsigned u = (unsigned)idx;
+    const unsigned i = u / (unsigned)ncols, j = u - i * ncols;
+    const float l = S[idx] * scale;
+    float g = expf(l - lse_own[i]) + expf(l - lse_other[j]);
+    if ((int)j == diag_off + (int)i) g -= 2.f;
+    g *= coef;
+    dls = fmaf(g, l, dls);
+    S[idx] = g * scale;
+  }
+  dls = wave_sum(dls);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dls;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 // ------------------------------------------------------------------------------------------------ SigLIP
 __device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 
@@ -270,6 +322,40 @@ int mpr_clip_bwd(float* S, const float* logit_scale, const float* row_lse, const
                                          1.f / (2.f * (float)n * (float)buckets));
   MPR_LAUNCH_CHECK("clip_grad_kernel");
   finish_sum_kernel<<<1, 256, 0, st>>>(workspace, grid, 1.f, gout, d_logit_scale, 0);
+  MPR_LAUNCH_CHECK("finish_sum_kernel");
+  return MPR_OK;
+}
+
+// Row-block (data-parallel) CLIP: S_blk [rows][ncols] = X_loc Y_all^T raw cosines, positives at column
+// diag_off + i.  sum_out[0] = sum_i (row_lse[i] - diag[i])  (un-normalised local part of the loss).
+int mpr_clip_block_fwd(const float* S, const float* logit_scale, float* row_lse, float* diag, float* sum_out,
+                       float* workspace, int rows, int ncols, int diag_off, void* stream) {
+  MPR_REQUIRE(S && logit_scale && row_lse && diag && sum_out && workspace, "mpr_clip_block_fwd: null pointer");
+  MPR_REQUIRE(diag_off >= 0 && diag_off + rows <= ncols, "mpr_clip_block_fwd: diagonal outside the block");
+  MPR_REQUIRE((long long)rows * ncols < (1ll << 32), "mpr_clip_block_fwd: block too large");
+  hipStream_t st = (hipStream_t)stream;
+  clip_block_row_lse_kernel<<<ceil_div(rows, 4), 256, 0, st>>>(S, logit_scale, row_lse, diag, rows, ncols, diag_off);
+  MPR_LAUNCH_CHECK("clip_block_row_lse_kernel");
+  // sum (row_lse - diag): reuse the squared-difference-free helper via two finishing sums
+  finish_sum_kernel<<<1, 256, 0, st>>>(row_lse, rows, 1.f, nullptr, sum_out, 0);
+  finish_sum_kernel<<<1, 256, 0, st>>>(diag, rows, -1.f, nullptr, sum_out, 1);
+  MPR_LAUNCH_CHECK("finish_sum_kernel");
+  return MPR_OK;
+}
+
+// S_blk <- dLoss/dS_raw (in place); d_logit_scale_part[0] = sum G*l over this block (x gout if given).
+int mpr_clip_block_bwd(float* S, const float* logit_scale, const float* lse_own, const float* lse_other,
+                       const float* gout, float coef, float* d_logit_scale_part, float* workspace, int rows,
+                       int ncols, int diag_off, void* stream) {
+  MPR_REQUIRE(S && logit_scale && lse_own && lse_other && d_logit_scale_part && workspace,
+              "mpr_clip_block_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)rows * ncols;
+  const int grid = (int)((total + 255) / 256 < LOSS_GRID ? (total + 255) / 256 : LOSS_GRID);
+  clip_block_grad_kernel<<<grid, 256, 0, st>>>(S, logit_scale, lse_own, lse_other, workspace, rows, ncols, diag_off,
+                                               coef);
+  MPR_LAUNCH_CHECK("clip_block_grad_kernel");
+  finish_sum_kernel<<<1, 256, 0, st>>>(workspace, grid, 1.f, gout, d_logit_scale_part, 0);
   MPR_LAUNCH_CHECK("finish_sum_kernel");
   return MPR_OK;
 }

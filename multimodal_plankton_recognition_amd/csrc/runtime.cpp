@@ -1,10 +1,23 @@
-// C-ABI runtime glue: error reporting and library identity.  No torch types anywhere in this library.
+// C-ABI runtime glue: error reporting, library identity and an opt-in per-kernel event profiler
+// (hipEvent pairs recorded on the launch stream around selected kernels, used by bench.py's roofline
+// line).  No torch types anywhere in this library.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 static thread_local char g_err[512] = "";
+
+struct ProfRec {
+  int kind;
+  double work;
+  hipEvent_t a, b;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
 
 extern "C" {
 
@@ -41,6 +54,77 @@ int mpr_device_check(char* name, int name_len) {
     mpr_set_error("device 0 is %s, this library is built for gfx950 only", prop.gcnArchName);
     return 1;
   }
+  return 0;
+}
+
+// ---- opt-in kernel profiler -------------------------------------------------------------------
+// kinds: 0 conv_igemm forward, 1 conv_igemm dgrad, 2 conv_wgrad, 3 stem fwd, 4 stem wgrad
+int mpr_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+
+int mpr_prof_reset(void) {
+  for (auto& r : g_prof) {
+    g_event_pool.push_back(r.a);
+    g_event_pool.push_back(r.b);
+  }
+  g_prof.clear();
+  return 0;
+}
+
+static hipEvent_t prof_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+// internal: called by the launch wrappers (not part of the public header)
+void* mpr_prof_begin(int kind, double work, void* stream) {
+  if (!g_prof_on) return nullptr;
+  ProfRec r;
+  r.kind = kind;
+  r.work = work;
+  r.a = prof_event();
+  r.b = prof_event();
+  hipEventRecord(r.a, (hipStream_t)stream);
+  g_prof.push_back(r);
+  return (void*)(uintptr_t)g_prof.size();
+}
+
+void mpr_prof_end(void* token, void* stream) {
+  if (!token) return;
+  ProfRec& r = g_prof[(size_t)(uintptr_t)token - 1];
+  hipEventRecord(r.b, (hipStream_t)stream);
+}
+
+// Sums over all recorded launches of `kind` (-1: every kind).  Synchronises on the recorded events.
+int mpr_prof_collect(int kind, double* total_ms, double* total_work, int* launches) {
+  double ms = 0.0, work = 0.0;
+  int n = 0;
+  for (auto& r : g_prof) {
+    if (kind >= 0 && r.kind != kind) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) {
+      mpr_set_error("mpr_prof_collect: hipEventSynchronize failed");
+      return 2;
+    }
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) {
+      mpr_set_error("mpr_prof_collect: hipEventElapsedTime failed");
+      return 2;
+    }
+    ms += t;
+    work += r.work;
+    ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_work) *total_work = work;
+  if (launches) *launches = n;
   return 0;
 }
 

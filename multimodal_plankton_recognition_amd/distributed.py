@@ -1,0 +1,197 @@
+"""Data-parallel train_multi over the 8 GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference is single-GPU; this is the build-side extension BASELINE config C4 asks
+for.  Samples are sharded over ranks (rank r owns rows [r*b, (r+1)*b) of the global batch), encoders
+and BatchNorm statistics are per rank, and the ONLY coupling is the global contrastive matrix:
+
+  1. all-gather of the L2-normalised embeddings  (2 x [b, D] fp32 per rank, one collective)
+  2. every rank forms only ITS row blocks  U_loc V_all^T  and  V_loc U_all^T  ([b, n] each, never the
+     n x n matrix), whose row log-sum-exps are local
+  3. all-gather of the two LSE vectors (2 x [b] fp32) -- the softmax over the other axis needs them
+  4. dL/dU_loc, dL/dV_loc are then computed locally against U_all / V_all (no reduce-scatter of
+     embedding gradients); the loss value and d(logit_scale) are summed over ranks
+  5. one SUM all-reduce of the flattened parameter gradients (the loss is already a mean over the
+     GLOBAL batch, so per-rank contributions add).
+
+`dp_clip` is written against a small "math" interface so that the exchange logic is exercised on CPU
+with gloo in tests (tests inject a torch-based math object); the product default is the HIP one and
+raises without the native library.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+from . import ops
+
+F32 = torch.float32
+
+
+# ------------------------------------------------------------------------------------------------ process group
+def init(device=None, backend=None):
+    if dist.is_initialized():
+        return
+    if backend is None:
+        backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    kw = {}
+    if backend == 'nccl' and device is not None:
+        kw['device_id'] = torch.device(device)
+    dist.init_process_group(backend=backend, rank=int(os.environ.get('RANK', 0)),
+                            world_size=int(os.environ.get('WORLD_SIZE', 1)), **kw)
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def barrier():
+    dist.barrier()
+
+
+def max_over_ranks(value: float) -> float:
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+class Comm:
+    """The two collectives the path needs."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_gather(self, x):
+        """[...] -> [world, ...] (rank-major)."""
+        x = x.contiguous()
+        out = torch.empty(self.world * x.numel(), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.reshape(-1), group=self.group)
+        return out.view((self.world,) + tuple(x.shape))
+
+    def all_reduce_sum(self, x):
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------ math back end
+class HipClipMath:
+    """The per-rank arithmetic of the sharded CLIP loss on the gfx950 kernels (no fallback)."""
+
+    def normalize(self, x):
+        x = x.detach().contiguous().float()
+        u = torch.empty_like(x)
+        inv = torch.empty(x.shape[0], dtype=F32, device=x.device)
+        N.call('mpr_l2norm_fwd', x, u, inv, x.shape[0], x.shape[1])
+        return u, inv
+
+    def logits(self, x_loc, y_all):
+        return ops.gemm(x_loc, y_all, trans_b=True)
+
+    def _ws(self, dev):
+        return torch.empty(N.query('mpr_loss_workspace_floats'), dtype=F32, device=dev)
+
+    def block_fwd(self, S, logit_scale, off):
+        rows, ncols = S.shape
+        lse = torch.empty(rows, dtype=F32, device=S.device)
+        diag = torch.empty(rows, dtype=F32, device=S.device)
+        total = torch.empty((), dtype=F32, device=S.device)
+        N.call('mpr_clip_block_fwd', S, logit_scale.detach(), lse, diag, total, self._ws(S.device), rows, ncols, off)
+        return lse, total
+
+    def block_bwd(self, S, logit_scale, lse_own, lse_other, off, coef):
+        rows, ncols = S.shape
+        dls = torch.empty((), dtype=F32, device=S.device)
+        N.call('mpr_clip_block_bwd', S, logit_scale.detach(), lse_own, lse_other, None, float(coef), dls,
+               self._ws(S.device), rows, ncols, off)
+        return dls
+
+    def matmul(self, g, y_all):
+        return ops.gemm(g, y_all)
+
+    def normalize_bwd(self, du, u, inv):
+        dx = torch.empty_like(u)
+        N.call('mpr_l2norm_bwd', du, u, inv, None, None, 0.0, None, dx, u.shape[0], u.shape[1])
+        return dx
+
+
+def dp_clip(image_emb, profile_emb, logit_scale, comm, math):
+    """Sharded CLIP loss (src/coordination.py:26-47 over the GLOBAL batch, buckets = 1).
+
+    Returns (loss [global value, identical on every rank], dL/d image_emb, dL/d profile_emb,
+    d logit_scale [this rank's partial: the total is the SUM over ranks])."""
+    b = image_emb.shape[0]
+    n = b * comm.world
+    off = comm.rank * b
+    u, iu = math.normalize(image_emb)
+    v, iv = math.normalize(profile_emb)
+    both = comm.all_gather(torch.stack((u, v)))                      # [world, 2, b, D]
+    D = u.shape[1]
+    u_all = both[:, 0].reshape(n, D).contiguous()
+    v_all = both[:, 1].reshape(n, D).contiguous()
+    s_img = math.logits(u, v_all)                                    # rows: my images,   cols: all profiles
+    s_prof = math.logits(v, u_all)                                   # rows: my profiles, cols: all images
+    lse_r, sum_r = math.block_fwd(s_img, logit_scale, off)
+    lse_c, sum_c = math.block_fwd(s_prof, logit_scale, off)
+    lses = comm.all_gather(torch.stack((lse_r, lse_c)))              # [world, 2, b]
+    lse_r_all = lses[:, 0].reshape(n).contiguous()
+    lse_c_all = lses[:, 1].reshape(n).contiguous()
+    loss = comm.all_reduce_sum(((sum_r + sum_c) / (2.0 * n)).reshape(1).clone()).reshape(())
+    coef = 1.0 / (2.0 * n)
+    dls = math.block_bwd(s_img, logit_scale, lse_r, lse_c_all, off, coef)      # s_img  <- G  * scale
+    math.block_bwd(s_prof, logit_scale, lse_c, lse_r_all, off, coef)           # s_prof <- G^T * scale (my columns)
+    d_img = math.normalize_bwd(math.matmul(s_img, v_all), u, iu)
+    d_prof = math.normalize_bwd(math.matmul(s_prof, u_all), v, iv)
+    return loss, d_img, d_prof, dls
+
+
+# ------------------------------------------------------------------------------------------------ DP step
+class DataParallelStep:
+    """zero_grad -> encode (local) -> sharded CLIP -> backward -> flat SUM all-reduce -> fused SGD."""
+
+    def __init__(self, model, optimizer, world, comm=None, math=None):
+        from .coordination import CLIPLoss
+        if not isinstance(model.loss, CLIPLoss):
+            raise NotImplementedError('data-parallel step: only method "clip" has a sharded loss so far')
+        self.model, self.opt = model, optimizer
+        self.comm = comm or Comm()
+        self.math = math or HipClipMath()
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self._flat = None
+        self._views = None
+
+    def _flat_views(self):
+        if self._flat is None:
+            sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]        # 16-byte aligned slots
+            self._flat = torch.zeros(sum(sizes), dtype=F32, device=self.params[0].device)
+            views, o = [], 0
+            for p, s in zip(self.params, sizes):
+                views.append(self._flat[o:o + p.numel()].view_as(p))
+                o += s
+            self._views = views
+        return self._flat, self._views
+
+    def step(self, batch):
+        model = self.model
+        self.opt.zero_grad()
+        if batch.get('buckets', 1) != 1:
+            raise NotImplementedError('data-parallel step: buckets must be 1 (the global batch is one bucket)')
+        emb = model.encode(**batch)
+        loss, d_img, d_prof, dls = dp_clip(emb['image_emb'], emb['profile_emb'], model.loss.logit_scale,
+                                           self.comm, self.math)
+        torch.autograd.backward([emb['image_emb'], emb['profile_emb']], [d_img, d_prof])
+        model.loss.logit_scale.grad = dls
+        flat, views = self._flat_views()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        torch._foreach_copy_(views, grads)
+        self.comm.all_reduce_sum(flat)
+        for p, v in zip(self.params, views):
+            p.grad = v
+        self.opt.step()
+        model.train_loss.append(loss.detach())
+        return loss

@@ -165,13 +165,13 @@ class _Classifier(_StepModule):
         return torch.tensor([lut[l] for l in label], dtype=torch.long, device=device)
 
     def training_step(self, batch, batch_idx):
-        logits = self.forward(**{k: v for k, v in batch.items() if k != 'label'})
+        logits = self.forward(**{k: v for k, v in batch.items() if k != 'label'})['logits']
         loss, _ = _CeFn.apply(logits, self._label_ids(batch['label'], logits.device))
         self.train_loss.append(loss.detach())
         return loss
 
     def validation_step(self, batch, batch_idx):
-        logits = self.forward(**{k: v for k, v in batch.items() if k != 'label'})
+        logits = self.forward(**{k: v for k, v in batch.items() if k != 'label'})['logits']
         y = self._label_ids(batch['label'], logits.device)
         loss, pred = _CeFn.apply(logits, y)
         self.valid_loss.append(loss.detach())
@@ -190,7 +190,7 @@ class _Classifier(_StepModule):
         self.valid_loss.clear(); self.valid_pred.clear(); self.valid_true.clear()
 
     def predict_step(self, batch, batch_idx, dataloader_idx=0):
-        logits = self.forward(**{k: v for k, v in batch.items() if k != 'label'})
+        logits = self.forward(**{k: v for k, v in batch.items() if k != 'label'})['logits']
         _, argmax, _ = ops.softmax_ce(logits.contiguous())
         return {'logits': logits, 'pred': argmax}
 
@@ -206,7 +206,7 @@ class ImageModel(_Classifier):
         self._init_head(self.image_encoder, class_names, optim_args)
 
     def forward(self, image, **kwargs):
-        return self._logits(self.image_encoder(image=image, **kwargs))
+        return {'logits': self._logits(self.image_encoder(image=image, **kwargs))}      # src/model.py:194-197
 
 
 class ProfileModel(_Classifier):
@@ -225,4 +225,4 @@ class ProfileModel(_Classifier):
         self._init_head(self.profile_encoder, class_names, optim_args)
 
     def forward(self, profile, **kwargs):
-        return self._logits(self.profile_encoder(profile=profile, **kwargs))
+        return {'logits': self._logits(self.profile_encoder(profile=profile, **kwargs))}  # src/model.py:350-353

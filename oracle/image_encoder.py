@@ -13,6 +13,7 @@ concat, image_encoder.py:23-29) IS restated from the reference source.
 import math
 import torch
 import torch.nn.functional as F
+from .rounding import r
 
 
 def _bn2d(sd, name, x, train):
@@ -24,22 +25,22 @@ def _bn2d(sd, name, x, train):
 
 
 def _basic_block_2d(sd, p, x, stride, train):
-    out = F.conv2d(x, sd[p + 'conv1.weight'], None, stride, 1)
-    out = F.relu(_bn2d(sd, p + 'bn1', out, train))
-    out = F.conv2d(out, sd[p + 'conv2.weight'], None, 1, 1)
+    out = r(F.conv2d(x, r(sd[p + 'conv1.weight']), None, stride, 1))
+    out = r(F.relu(_bn2d(sd, p + 'bn1', out, train)))
+    out = r(F.conv2d(out, r(sd[p + 'conv2.weight']), None, 1, 1))
     out = _bn2d(sd, p + 'bn2', out, train)
     if (p + 'downsample.0.weight') in sd:
-        sc = F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride, 0)
-        sc = _bn2d(sd, p + 'downsample.1', sc, train)
+        sc = r(F.conv2d(x, r(sd[p + 'downsample.0.weight']), None, stride, 0))
+        sc = r(_bn2d(sd, p + 'downsample.1', sc, train))
     else:
         sc = x
-    return F.relu(out + sc)
+    return r(F.relu(out + sc))
 
 
 def resnet_features(sd, image, blocks=(2, 2, 2, 2), train=False, prefix=''):
     """ResNet BasicBlock backbone, pooled features [B, 512]."""
-    x = F.conv2d(image, sd[prefix + 'conv1.weight'], None, 2, 3)
-    x = F.relu(_bn2d(sd, prefix + 'bn1', x, train))
+    x = r(F.conv2d(image, sd[prefix + 'conv1.weight'], None, 2, 3))     # stem: fp32 operands
+    x = r(F.relu(_bn2d(sd, prefix + 'bn1', x, train)))
     x = F.max_pool2d(x, 3, 2, 1)
     for li, reps in enumerate(blocks, start=1):
         for bi in range(reps):

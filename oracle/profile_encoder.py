@@ -10,6 +10,7 @@ applied (parity runs use p=0 / eval, SURVEY section 7 'Dropout parity').
 import math
 import torch
 import torch.nn.functional as F
+from .rounding import r
 
 
 def _bn(sd, name, x, train):
@@ -23,23 +24,23 @@ def _bn(sd, name, x, train):
 
 def _basic_block_1d(sd, p, x, stride, train):
     # _BasicBlock.forward, profile_encoder.py:132-148
-    out = F.conv1d(x, sd[p + 'conv1.weight'], None, stride, 1)
-    out = F.relu(_bn(sd, p + 'bn1', out, train))
-    out = F.conv1d(out, sd[p + 'conv2.weight'], None, 1, 1)
+    out = r(F.conv1d(x, r(sd[p + 'conv1.weight']), None, stride, 1))
+    out = r(F.relu(_bn(sd, p + 'bn1', out, train)))
+    out = r(F.conv1d(out, r(sd[p + 'conv2.weight']), None, 1, 1))
     out = _bn(sd, p + 'bn2', out, train)
     if (p + 'downsample.0.weight') in sd:
-        identity = F.conv1d(x, sd[p + 'downsample.0.weight'], None, stride, 0)
-        identity = _bn(sd, p + 'downsample.1', identity, train)
+        identity = r(F.conv1d(x, r(sd[p + 'downsample.0.weight']), None, stride, 0))
+        identity = r(_bn(sd, p + 'downsample.1', identity, train))
     else:
         identity = x
-    return F.relu(out + identity)
+    return r(F.relu(out + identity))
 
 
 def profile_cnn_features(sd, profile, blocks, train=False, prefix=''):
     """ProfileCNN.forward_features, profile_encoder.py:213-226.  profile: [B, L, dim_in]."""
     x = profile.transpose(1, 2)
-    x = F.conv1d(x, sd[prefix + 'conv1.weight'], None, 2, 1)        # :167
-    x = F.relu(_bn(sd, prefix + 'bn1', x, train))
+    x = r(F.conv1d(x, sd[prefix + 'conv1.weight'], None, 2, 1))     # :167 (stem: fp32 operands)
+    x = r(F.relu(_bn(sd, prefix + 'bn1', x, train)))
     x = F.max_pool1d(x, 3, 2, 1)                                     # :170
     for li, reps in enumerate(blocks, start=1):
         for bi in range(reps):
