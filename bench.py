@@ -36,6 +36,18 @@ def synthetic_batch(B, T, device, seed):
     return {'image': image, 'profile': profile, 'image_shape': image_shape, 'profile_len': profile_len}
 
 
+def host_cores():
+    """CPU share of this process: the cgroup quota when there is one (a 1-GPU box gets 16 of the node's cores)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(card, T, threads):
     """Oracle (CPU restatement) timed on a bounded sample of the same workload: batch 32 instead of 512."""
     from oracle import model as OM
@@ -128,7 +140,7 @@ def main():
     lib.mpr_prof_enable(0)
     if world > 1:
         elapsed = D.max_over_ranks(elapsed)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
 
     def collect(kind):
         ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
@@ -161,7 +173,8 @@ def main():
                                           'launches': n_w, 'share_of_step_time': round(ms_w / args.steps / ms_per_step, 3)}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            # host share of a 1-GPU box is 16 cores (the node reports all of them): never oversubscribe
+            threads = host_cores()
             out['cpu_baseline'] = cpu_baseline(card, T, threads)
         print(json.dumps(out), flush=True)
     if world > 1:

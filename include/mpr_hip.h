@@ -40,7 +40,10 @@ int mpr_prof_collect(int kind, double* total_ms, double* total_work, int* launch
 int mpr_conv_packed_sizes(int K, int C, int R, int S, long long* fwd_elems, long long* dgrad_elems);
 int mpr_conv_pack_weights(const float* w_oihw, void* w_fwd, void* w_dgrad /* may be NULL */, int K, int C, int R,
                           int S, void* stream);
-int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K);
+int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C);
+/* rows (B*P*Q) from which the LDS-DMA ring kernel replaces the register-staged one (default 32768);
+ * returns the previous threshold */
+int mpr_conv_set_dma_min_rows(int rows);
 int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may be NULL */, int B, int H, int W,
                  int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
 int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add /* may be NULL */, int B, int H,

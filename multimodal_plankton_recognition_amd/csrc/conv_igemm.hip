@@ -228,6 +228,214 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGemmParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (source channels a multiple of 64, i.e. every K chunk is one tap x 64 channels).
+// Operand tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no ds_write), into a
+// ring of STAGES buffers; a chunk is issued STAGES-1 chunks ahead and retired by a COUNTED s_waitcnt vmcnt
+// followed by one raw s_barrier per chunk (a __syncthreads() would drain the DMA queue).  The LDS image
+// of a DMA instruction is lane-linear (64 lanes x 16 B = 8 rows x 128 B), so the bank swizzle is applied
+// on the SOURCE side: lane (row, physical chunk) fetches logical chunk = physical ^ ((row >> 1) & 7), and
+// the fragment reads use the same XOR.  Padding taps / stride holes / the M tail read a 64-B zero page.
+__device__ uint4 g_zero_page[4];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WM, int WN, int STAGES, bool DGRAD>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const ConvGemmParams p) {
+  constexpr int NW = WM * WN, T = 64 * NW;
+  constexpr int BM = WM * 64, BN = WN * 64;
+  constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, IPC = A_IT + B_IT;
+  static_assert(A_IT % 2 == 0 && B_IT % 2 == 0, "instruction parity must follow the local index");
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int CS_STRIDE = BN * 4 + 16;
+  static_assert(STAGES * STAGE >= BM * CS_STRIDE, "epilogue tile must fit the ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / p.ntn, nt = bid - mt * p.ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // DMA geometry: instruction I covers tile rows 8I..8I+7; lane -> (row 8I + lane/8, physical chunk lane%8)
+  const int lrow = lane >> 3;
+  const int lc_even = (lane & 7) ^ (lane >> 4);        // logical chunk for even I; odd I: ^ 4
+  int rbase[A_IT], rh[A_IT], rw[A_IT];
+#pragma unroll
+  for (int j = 0; j < A_IT; ++j) {
+    const int m = m0 + 8 * (wid * A_IT + j) + lrow;
+    if (m < p.M) {
+      const uint32_t b = fdiv(m, p.div_pq);
+      const uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
+      const uint32_t pp = fdiv(rem, p.div_q);
+      const uint32_t qq = rem - pp * p.Qm;
+      rbase[j] = b * p.sH * p.sW;
+      if (!DGRAD) { rh[j] = (int)pp * p.sh - p.ph; rw[j] = (int)qq * p.sw - p.pw; }
+      else        { rh[j] = (int)pp + p.ph;        rw[j] = (int)qq + p.pw; }
+    } else {
+      rbase[j] = 0; rh[j] = -(1 << 20); rw[j] = -(1 << 20);
+    }
+  }
+  const bf16_t* wrow[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j)
+    wrow[j] = p.wpk + (size_t)(n0 + 8 * (wid * B_IT + j) + lrow) * p.Kgpad + (lc_even ^ ((j & 1) << 2)) * 8;
+
+  const int ncb = p.sC >> 6;     // 64-channel blocks per tap
+  int tr = 0, ts = 0, cb = 0;    // wave-uniform tap state of the NEXT chunk to issue
+  auto issue_chunk = [&](int kc, int buf) {
+    unsigned char* sa = smem + buf * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+    const bool tap_ok = tr < p.R;
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+      bool ok;
+      int pix;
+      if (!DGRAD) {
+        const int ih = rh[j] + tr, iw = rw[j] + ts;
+        ok = tap_ok && (unsigned)ih < (unsigned)p.sH && (unsigned)iw < (unsigned)p.sW;
+        pix = rbase[j] + ih * p.sW + iw;
+      } else {
+        int oh = rh[j] - tr, ow = rw[j] - ts;
+        ok = tap_ok && oh >= 0 && ow >= 0;
+        if (p.sh == 2) { ok = ok && !(oh & 1); oh >>= 1; }
+        if (p.sw == 2) { ok = ok && !(ow & 1); ow >>= 1; }
+        ok = ok && oh < p.sH && ow < p.sW;
+        pix = rbase[j] + oh * p.sW + ow;
+      }
+      const int lc = lc_even ^ ((j & 1) << 2);
+      const bf16_t* src = ok ? p.src + ((size_t)pix * p.sC + cb * 64 + lc * 8)
+                             : reinterpret_cast<const bf16_t*>(g_zero_page);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + (wid * A_IT + j) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[j] + (size_t)kc * 64),
+                                       (__attribute__((address_space(3))) void*)(sb + (wid * B_IT + j) * 1024), 16, 0, 0);
+    if (++cb == ncb) { cb = 0; if (++ts == p.S) { ts = 0; ++tr; } }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int issued = 0;
+  for (; issued < STAGES - 1 && issued < p.nk; ++issued) issue_chunk(issued, issued % STAGES);
+
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int kc = 0; kc < p.nk; ++kc) {
+    // retire chunk kc: everything but the (issued - kc - 1) younger chunks of THIS wave must have landed
+    const int younger = issued - kc - 1;
+    if (STAGES >= 3 && younger >= STAGES - 2) wait_vmcnt<(STAGES - 2) * IPC>();
+    else if (STAGES >= 4 && younger == STAGES - 3) wait_vmcnt<(STAGES >= 4 ? (STAGES - 3) : 0) * IPC>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (issued < p.nk) { issue_chunk(issued, issued % STAGES); ++issued; }
+    const unsigned char* a = smem + (kc % STAGES) * STAGE;
+    const unsigned char* b = a + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = *reinterpret_cast<const bf16x8*>(a + swz_off(wm * 64 + t * 32 + frow, ks * 2 + fh));
+        bfr[t] = *reinterpret_cast<const bf16x8*>(b + swz_off(wn * 64 + t * 32 + frow, ks * 2 + fh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue (as the register-staged kernel): fp32 tile -> LDS -> 16-B channel groups
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wm * 64 + j * 32 + frow;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wn * 64 + i * 32 + 8 * g + 4 * fh;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
+      }
+    }
+  __syncthreads();
+
+  constexpr int CPR = BN / 8;
+  constexpr int RPP = T / CPR;
+  const int ch = tid % CPR, rr = tid / CPR;
+  const int ncol = n0 + ch * 8;
+  const bool col_ok = ncol < p.Nout;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll 4
+  for (int r = rr; r < BM; r += RPP) {
+    const int m = m0 + r;
+    if (m < p.M && col_ok) {
+      const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
+      const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
+      float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const size_t o = (size_t)m * p.Nout + ncol;
+      if (p.add) {
+        float g[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.add + o), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += g[e];
+      }
+      const uint4 pk = pack8(f);
+      *reinterpret_cast<uint4*>(p.dst + o) = pk;
+      if (p.stats) {
+        float q[8];
+        unpack8(pk, q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+      }
+    }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [NW waves][CPR][16]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wid * CPR + lane) * 16 + e] = s1[e];
+        red[(wid * CPR + lane) * 16 + 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < CPR * 16) {
+      const int c = tid >> 4, e = tid & 15;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[(w * CPR + c) * 16 + e];
+      const int n = n0 + c * 8 + (e & 7);
+      if (n < p.Nout) p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing:  OIHW fp32  ->  Wf [Kpad128][ceil64(R*S*C)]  and  Wd [Cpad128][ceil64(R*S*K)]  bf16
 __global__ void conv_pack_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf,
                                          bf16_t* __restrict__ wd, int K, int C, int R, int S,
@@ -279,15 +487,51 @@ int mpr_conv_pack_weights(const float* w_oihw, void* w_fwd, void* w_dgrad, int K
   return MPR_OK;
 }
 
+// Kernel / tile selection, shared by the launcher and the stat-row query.
+//   mode 1: LDS-DMA ring  (source channels % 64 == 0 and enough rows to fill the chip)
+//   mode 0: register-staged kernel (any channel count that is a multiple of 8; small problems)
+static int g_dma_min_rows = 32768;
+extern "C" int mpr_conv_set_dma_min_rows(int rows) {   // tuning / test knob; returns the previous value
+  const int old = g_dma_min_rows;
+  g_dma_min_rows = rows;
+  return old;
+}
+
+static inline void igemm_config(long long M, int Nout, int srcC, int* mode, int* BM, int* BN) {
+  const bool narrow = Nout <= 64;
+  if (srcC % 64 == 0 && M >= g_dma_min_rows) {
+    *mode = 1; *BM = 256; *BN = narrow ? 64 : 128;
+  } else {
+    *mode = 0; *BM = narrow ? 256 : 128; *BN = narrow ? 64 : 128;
+  }
+}
+
 static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
-  // tile choice: N <= 64 -> 256x64 (all four waves along M), else 128x128
-  const bool narrow = p.Nout <= 64;
-  const int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
+  int mode, BM, BN;
+  igemm_config(p.M, p.Nout, p.sC, &mode, &BM, &BN);
+  const bool narrow = BN == 64;
   p.ntn = ceil_div(p.Nout, BN);
   const int gm = ceil_div(p.M, BM);
-  const size_t stage2 = (size_t)2 * (BM + BN) * 128, epi = (size_t)BM * (BN * 4 + 16);
-  const size_t smem = stage2 > epi ? stage2 : epi;
   dim3 grid(gm * p.ntn);
+  void* tok = mpr_prof_begin(dgrad ? 1 : 0, 2.0 * (double)p.M * (double)p.Nout * (double)p.Kg, st);
+  if (mode == 1) {
+#define MPR_DMA(WM_, WN_, ST_, DG_)                                                                   \
+  do {                                                                                                \
+    static bool attr_set = false;                                                                     \
+    if (!attr_set) {                                                                                  \
+      hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<WM_, WN_, ST_, DG_>,                     \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      attr_set = true;                                                                                \
+    }                                                                                                 \
+    conv_igemm_dma_kernel<WM_, WN_, ST_, DG_>                                                         \
+        <<<grid, 64 * WM_ * WN_, (size_t)ST_ * (64 * WM_ + 64 * WN_) * 128, st>>>(p);                 \
+  } while (0)
+    if (narrow) { if (dgrad) MPR_DMA(4, 1, 2, true); else MPR_DMA(4, 1, 2, false); }
+    else        { if (dgrad) MPR_DMA(4, 2, 3, true); else MPR_DMA(4, 2, 3, false); }
+#undef MPR_DMA
+  } else {
+    const size_t stage2 = (size_t)2 * (BM + BN) * 128, epi = (size_t)BM * (BN * 4 + 16);
+    const size_t smem = stage2 > epi ? stage2 : epi;
 #define MPR_IGEMM(WM_, WN_, DG_)                                                                      \
   do {                                                                                                \
     static bool attr_set = false;                                                                     \
@@ -298,18 +542,20 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
     }                                                                                                 \
     conv_igemm_kernel<WM_, WN_, DG_><<<grid, 256, smem, st>>>(p);                                     \
   } while (0)
-  void* tok = mpr_prof_begin(dgrad ? 1 : 0, 2.0 * (double)p.M * (double)p.Nout * (double)p.Kg, st);
-  if (narrow) { if (dgrad) MPR_IGEMM(4, 1, true); else MPR_IGEMM(4, 1, false); }
-  else        { if (dgrad) MPR_IGEMM(2, 2, true); else MPR_IGEMM(2, 2, false); }
+    if (narrow) { if (dgrad) MPR_IGEMM(4, 1, true); else MPR_IGEMM(4, 1, false); }
+    else        { if (dgrad) MPR_IGEMM(2, 2, true); else MPR_IGEMM(2, 2, false); }
 #undef MPR_IGEMM
+  }
   mpr_prof_end(tok, st);
   MPR_LAUNCH_CHECK("conv_igemm_kernel");
   return MPR_OK;
 }
 
 // Number of row tiles (= rows of the BatchNorm partial-sum buffer) mpr_conv_fwd will use.
-int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K) {
-  return ceil_div(B * P * Q, K <= 64 ? 256 : 128);
+int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C) {
+  int mode, BM, BN;
+  igemm_config((long long)B * P * Q, K, C, &mode, &BM, &BN);
+  return ceil_div(B * P * Q, BM);
 }
 
 // y[B,P,Q,K] = conv(x[B,H,W,C], w) ; stats (optional): [mpr_conv_fwd_stat_rows][2][K] fp32 partial sums

@@ -49,16 +49,17 @@ _pack_cache = {}
 
 def packed_weights(weight, geom, need_dgrad=True):
     """bf16 GEMM panels of an fp32 OIHW weight, cached on (storage, version)."""
-    key = (weight.data_ptr(), weight._version, need_dgrad)
-    hit = _pack_cache.get(id(weight))
-    if hit is not None and hit[0] == key:
+    # the cache entry lives ON the tensor object (dies with it: no id()/address aliasing between tensors)
+    key = (weight.data_ptr(), weight._version)
+    hit = getattr(weight, '_mpr_packed', None)
+    if hit is not None and hit[0] == key and (hit[2] is not None or not need_dgrad):
         return hit[1], hit[2]
     nf = (geom.K + 127) // 128 * 128 * ((geom.R * geom.S * geom.C + 63) // 64 * 64)
     nd = (geom.C + 127) // 128 * 128 * ((geom.R * geom.S * geom.K + 63) // 64 * 64)
     wf = torch.empty(nf, dtype=BF16, device=weight.device)
     wd = torch.empty(nd, dtype=BF16, device=weight.device) if need_dgrad else None
     N.call('mpr_conv_pack_weights', weight.detach(), wf, wd, geom.K, geom.C, geom.R, geom.S)
-    _pack_cache[id(weight)] = (key, wf, wd)
+    weight._mpr_packed = (key, wf, wd)
     return wf, wd
 
 
@@ -70,7 +71,7 @@ def conv_fwd(x, wf, g, want_stats):
     y = torch.empty(_like_spatial(x, B, P, Q, g.K), dtype=BF16, device=x.device)
     stats = None
     if want_stats:
-        rows = N.query('mpr_conv_fwd_stat_rows', B, P, Q, g.K)
+        rows = N.query('mpr_conv_fwd_stat_rows', B, P, Q, g.K, C)
         stats = torch.empty(rows, 2, g.K, dtype=F32, device=x.device)
     N.call('mpr_conv_fwd', x, wf, y, stats, B, H, W, C, g.K, *g.tail)
     return y, stats

@@ -52,7 +52,7 @@ def profile_cnn_features(sd, profile, blocks, train=False, prefix=''):
 def profile_cnn_forward(sd, profile, profile_len, blocks, train=False, metadata=True, prefix=''):
     """ProfileCNN.forward, profile_encoder.py:229-240 (AdaptiveMaxPool1d named 'avgpool' :177)."""
     x = profile_cnn_features(sd, profile, blocks, train, prefix)
-    x = x.amax(dim=2)
+    x = F.adaptive_max_pool1d(x, 1).flatten(1)      # :177,232-233 (single arg-max gets the gradient)
     if metadata:
         meta = profile_len.to(profile.dtype) / profile.shape[1]     # :236-237
         x = torch.cat((x, meta), 1)

@@ -51,8 +51,17 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=['regs', 'dma'])
+def igemm_path(request):
+    """Run the conv tests through both implicit-GEMM kernels (register-staged / LDS-DMA ring)."""
+    from multimodal_plankton_recognition_amd import _native
+    old = _native.query('mpr_conv_set_dma_min_rows', 0 if request.param == 'dma' else 1 << 30)
+    yield request.param
+    _native.query('mpr_conv_set_dma_min_rows', old)
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv2d_fwd_dgrad_wgrad(case):
+def test_conv2d_fwd_dgrad_wgrad(case, igemm_path):
     ops = _ops()
     B, H, W, C, K, R, stride, pad = case
     x = bf(rnd(B, C, H, W, seed=1)).float()
@@ -86,7 +95,7 @@ def test_conv2d_fwd_dgrad_wgrad(case):
 
 @pytest.mark.parametrize('case', [(3, 40, 32, 32, 3, 1, 1), (2, 33, 32, 64, 3, 2, 1), (4, 17, 64, 128, 1, 2, 0),
                                   (2, 24, 8, 8, 3, 1, 1)])
-def test_conv1d_fwd_dgrad_wgrad(case):
+def test_conv1d_fwd_dgrad_wgrad(case, igemm_path):
     ops = _ops()
     B, L, C, K, S, stride, pad = case
     x = bf(rnd(B, C, L, seed=5)).float()
@@ -106,7 +115,7 @@ def test_conv1d_fwd_dgrad_wgrad(case):
     np.testing.assert_allclose(dw.cpu().numpy(), wg.grad.numpy(), rtol=2e-3, atol=2e-3 * float(wg.grad.abs().max()))
 
 
-def test_conv_large_rows_many_tiles():
+def test_conv_large_rows_many_tiles(igemm_path):
     """More than one wave of workgroups, M not a multiple of the tile, ResNet layer1 shape."""
     ops = _ops()
     B, H, W, C, K = 6, 56, 56, 64, 64
