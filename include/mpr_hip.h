@@ -40,8 +40,8 @@ int mpr_prof_collect(int kind, double* total_ms, double* total_work, int* launch
 int mpr_conv_packed_sizes(int K, int C, int R, int S, long long* fwd_elems, long long* dgrad_elems);
 int mpr_conv_pack_weights(const float* w_oihw, void* w_fwd, void* w_dgrad /* may be NULL */, int K, int C, int R,
                           int S, void* stream);
-int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C);
-/* rows (B*P*Q) from which the LDS-DMA ring kernel replaces the register-staged one (default 32768);
+int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S);
+/* rows (B*P*Q) from which the LDS-DMA ring kernel replaces the register-staged one (default 16384);
  * returns the previous threshold */
 int mpr_conv_set_dma_min_rows(int rows);
 int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may be NULL */, int B, int H, int W,
@@ -54,6 +54,11 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace /* K*R*S*C fl
 
 /* ---- stem convolutions (few input channels, fp32 input, direct) -----------------------------
  * timm ResNet conv1 (1->64, 7x7/2) and ProfileCNN.conv1 (src/profile_encoder.py:167). */
+/* ResNet stem as space-to-depth (7x7/2 on 1 channel == 4x4/1 on the 4 (+4 zero) phase channels, halo
+ * materialised): the conv itself then runs on mpr_conv_fwd / mpr_conv_wgrad with C=8, R=S=4, pad 0 */
+int mpr_stem_s2d(const float* x, void* xs /* [B][H/2+3][W/2+3][8] bf16 */, int B, int H, int W, void* stream);
+int mpr_stem_w_s2d(const float* w /* [K][1][7][7] */, float* w2 /* [K][8][4][4] */, int K, void* stream);
+int mpr_stem_dw_gather(const float* dw2, float* dw, int K, int accumulate, void* stream);
 int mpr_stem_fwd_stat_rows(int B, int P, int Q, int K);
 int mpr_stem_fwd(const float* x, const float* w_oihw, void* y, float* stats /* may be NULL */, int B, int H, int W,
                  int Cin, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);

@@ -25,6 +25,7 @@ struct ConvGemmParams {
   const bf16_t* add;   // optional [M][Nout]
   float* stats;        // optional [gridM][2][Nout]
   int sH, sW, sC;
+  unsigned src_bytes, wpk_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
   int M, Nout, Kg, Kgpad, nk, ntn;
   int R, S, sh, sw, ph, pw;
   FastDiv div_pq, div_q;   // row m -> (b, p, q)
@@ -229,13 +230,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGemmParams p)
 
 // ------------------------------------------------------------------------------------------------
 // LDS-DMA variant (source channels a multiple of 64, i.e. every K chunk is one tap x 64 channels).
-// Operand tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no ds_write), into a
+// Operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write), into a
 // ring of STAGES buffers; a chunk is issued STAGES-1 chunks ahead and retired by a COUNTED s_waitcnt vmcnt
 // followed by one raw s_barrier per chunk (a __syncthreads() would drain the DMA queue).  The LDS image
 // of a DMA instruction is lane-linear (64 lanes x 16 B = 8 rows x 128 B), so the bank swizzle is applied
 // on the SOURCE side: lane (row, physical chunk) fetches logical chunk = physical ^ ((row >> 1) & 7), and
-// the fragment reads use the same XOR.  Padding taps / stride holes / the M tail read a 64-B zero page.
-__device__ uint4 g_zero_page[4];
+// the fragment reads use the same XOR.  Padding taps / stride holes / the M tail are given an out-of-range
+// buffer offset: the descriptor's range check turns those lanes into zero writes.
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -244,6 +245,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <int WM, int WN, int STAGES, bool DGRAD>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const ConvGemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass of hipcc
   constexpr int NW = WM * WN, T = 64 * NW;
   constexpr int BM = WM * 64, BN = WN * 64;
   constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, IPC = A_IT + B_IT;
@@ -261,62 +263,78 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   const int m0 = mt * BM, n0 = nt * BN;
 
   // DMA geometry: instruction I covers tile rows 8I..8I+7; lane -> (row 8I + lane/8, physical chunk lane%8)
+  // Source addressing is linear in the tap: byte offset = row part (VGPR, fixed) + tap part (SGPR, per chunk);
+  // validity of each of the <= 32 taps for a row is one bit of a per-row mask, and invalid lanes get an
+  // out-of-range buffer offset, for which the hardware range check makes the DMA write zeros.
   const int lrow = lane >> 3;
   const int lc_even = (lane & 7) ^ (lane >> 4);        // logical chunk for even I; odd I: ^ 4
-  int rbase[A_IT], rh[A_IT], rw[A_IT];
+  //   fwd  : pix = rbase + (rh + r)*sW + (rw + s)                      -> ch =  2*sC*sW,      cw =  2*sC
+  //   dgrad: pix = rbase + ((rh - r)/sh)*sW + (rw - s)/sw  (when valid) -> ch = -2*sC*sW/sh,  cw = -2*sC/sw
+  const int tstep_h = DGRAD ? -(2 * p.sC * p.sW) / p.sh : 2 * p.sC * p.sW;
+  const int tstep_w = DGRAD ? -(2 * p.sC) / p.sw : 2 * p.sC;
+  uint32_t voff[A_IT], vmask[A_IT];
 #pragma unroll
   for (int j = 0; j < A_IT; ++j) {
     const int m = m0 + 8 * (wid * A_IT + j) + lrow;
+    voff[j] = 0;
+    vmask[j] = 0;
     if (m < p.M) {
       const uint32_t b = fdiv(m, p.div_pq);
       const uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
       const uint32_t pp = fdiv(rem, p.div_q);
       const uint32_t qq = rem - pp * p.Qm;
-      rbase[j] = b * p.sH * p.sW;
-      if (!DGRAD) { rh[j] = (int)pp * p.sh - p.ph; rw[j] = (int)qq * p.sw - p.pw; }
-      else        { rh[j] = (int)pp + p.ph;        rw[j] = (int)qq + p.pw; }
-    } else {
-      rbase[j] = 0; rh[j] = -(1 << 20); rw[j] = -(1 << 20);
+      int rh, rw;
+      if (!DGRAD) { rh = (int)pp * p.sh - p.ph; rw = (int)qq * p.sw - p.pw; }
+      else        { rh = (int)pp + p.ph;        rw = (int)qq + p.pw; }
+      const int lc = lc_even ^ ((j & 1) << 2);
+      voff[j] = (uint32_t)(b * p.sH * p.sW) * (uint32_t)(2 * p.sC) + (uint32_t)(rh * (DGRAD ? -tstep_h : tstep_h)) +
+                (uint32_t)(rw * (DGRAD ? -tstep_w : tstep_w)) + (uint32_t)(lc * 16);
+      uint32_t mk = 0;
+      for (int r = 0, t = 0; r < p.R; ++r)
+        for (int s2 = 0; s2 < p.S; ++s2, ++t) {
+          bool ok;
+          if (!DGRAD) {
+            ok = (unsigned)(rh + r) < (unsigned)p.sH && (unsigned)(rw + s2) < (unsigned)p.sW;
+          } else {
+            int oh = rh - r, ow = rw - s2;
+            ok = oh >= 0 && ow >= 0;
+            if (p.sh == 2) { ok = ok && !(oh & 1); oh >>= 1; }
+            if (p.sw == 2) { ok = ok && !(ow & 1); ow >>= 1; }
+            ok = ok && oh < p.sH && ow < p.sW;
+          }
+          mk |= (ok ? 1u : 0u) << t;
+        }
+      vmask[j] = mk;
     }
   }
-  const bf16_t* wrow[B_IT];
+  uint32_t boff[B_IT];
 #pragma unroll
   for (int j = 0; j < B_IT; ++j)
-    wrow[j] = p.wpk + (size_t)(n0 + 8 * (wid * B_IT + j) + lrow) * p.Kgpad + (lc_even ^ ((j & 1) << 2)) * 8;
+    boff[j] = ((uint32_t)(n0 + 8 * (wid * B_IT + j) + lrow) * (uint32_t)p.Kgpad + (lc_even ^ ((j & 1) << 2)) * 8) * 2;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, p.wpk_bytes, 0x00020000);
 
   const int ncb = p.sC >> 6;     // 64-channel blocks per tap
-  int tr = 0, ts = 0, cb = 0;    // wave-uniform tap state of the NEXT chunk to issue
+  const int ntaps = p.R * p.S;
+  int tr = 0, ts = 0, cb = 0, tap = 0;    // wave-uniform tap state of the NEXT chunk to issue
   auto issue_chunk = [&](int kc, int buf) {
     unsigned char* sa = smem + buf * STAGE;
     unsigned char* sb = sa + A_BYTES;
-    const bool tap_ok = tr < p.R;
+    const uint32_t toff = (uint32_t)(tr * tstep_h + ts * tstep_w + cb * 128);
+    const uint32_t bit = tap < ntaps ? (1u << tap) : 0u;      // K padding chunks: every lane reads zeros
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
-      bool ok;
-      int pix;
-      if (!DGRAD) {
-        const int ih = rh[j] + tr, iw = rw[j] + ts;
-        ok = tap_ok && (unsigned)ih < (unsigned)p.sH && (unsigned)iw < (unsigned)p.sW;
-        pix = rbase[j] + ih * p.sW + iw;
-      } else {
-        int oh = rh[j] - tr, ow = rw[j] - ts;
-        ok = tap_ok && oh >= 0 && ow >= 0;
-        if (p.sh == 2) { ok = ok && !(oh & 1); oh >>= 1; }
-        if (p.sw == 2) { ok = ok && !(ow & 1); ow >>= 1; }
-        ok = ok && oh < p.sH && ow < p.sW;
-        pix = rbase[j] + oh * p.sW + ow;
-      }
-      const int lc = lc_even ^ ((j & 1) << 2);
-      const bf16_t* src = ok ? p.src + ((size_t)pix * p.sC + cb * 64 + lc * 8)
-                             : reinterpret_cast<const bf16_t*>(g_zero_page);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sa + (wid * A_IT + j) * 1024), 16, 0, 0);
+      const uint32_t v = (vmask[j] & bit) ? voff[j] + toff : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(sa + (wid * A_IT + j) * 1024),
+                                               16, v, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[j] + (size_t)kc * 64),
-                                       (__attribute__((address_space(3))) void*)(sb + (wid * B_IT + j) * 1024), 16, 0, 0);
-    if (++cb == ncb) { cb = 0; if (++ts == p.S) { ts = 0; ++tr; } }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(sb + (wid * B_IT + j) * 1024),
+                                               16, boff[j], kc * 128, 0, 0);
+    if (++cb == ncb) { cb = 0; ++tap; if (++ts == p.S) { ts = 0; ++tr; } }
   };
 
   f32x16 acc[2][2];
@@ -331,6 +349,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   for (; issued < STAGES - 1 && issued < p.nk; ++issued) issue_chunk(issued, issued % STAGES);
 
   const int frow = lane & 31, fh = lane >> 5;
+  // fragment read offsets inside a stage: row*128 + (((2*ks + fh) ^ key) << 4), key = (row >> 1) & 7 = (frow >> 1) & 7
+  uint32_t a_rd[2][4], b_rd[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      a_rd[t][ks] = swz_off(wm * 64 + t * 32 + frow, ks * 2 + fh);
+      b_rd[t][ks] = A_BYTES + swz_off(wn * 64 + t * 32 + frow, ks * 2 + fh);
+    }
   for (int kc = 0; kc < p.nk; ++kc) {
     // retire chunk kc: everything but the (issued - kc - 1) younger chunks of THIS wave must have landed
     const int younger = issued - kc - 1;
@@ -341,14 +368,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     asm volatile("" ::: "memory");
     if (issued < p.nk) { issue_chunk(issued, issued % STAGES); ++issued; }
     const unsigned char* a = smem + (kc % STAGES) * STAGE;
-    const unsigned char* b = a + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        af[t] = *reinterpret_cast<const bf16x8*>(a + swz_off(wm * 64 + t * 32 + frow, ks * 2 + fh));
-        bfr[t] = *reinterpret_cast<const bf16x8*>(b + swz_off(wn * 64 + t * 32 + frow, ks * 2 + fh));
+        af[t] = *reinterpret_cast<const bf16x8*>(a + a_rd[t][ks]);
+        bfr[t] = *reinterpret_cast<const bf16x8*>(a + b_rd[t][ks]);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -433,6 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
       if (n < p.Nout) p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
     }
   }
+#endif   // __HIP_DEVICE_COMPILE__
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -490,16 +517,16 @@ int mpr_conv_pack_weights(const float* w_oihw, void* w_fwd, void* w_dgrad, int K
 // Kernel / tile selection, shared by the launcher and the stat-row query.
 //   mode 1: LDS-DMA ring  (source channels % 64 == 0 and enough rows to fill the chip)
 //   mode 0: register-staged kernel (any channel count that is a multiple of 8; small problems)
-static int g_dma_min_rows = 32768;
+static int g_dma_min_rows = 16384;
 extern "C" int mpr_conv_set_dma_min_rows(int rows) {   // tuning / test knob; returns the previous value
   const int old = g_dma_min_rows;
   g_dma_min_rows = rows;
   return old;
 }
 
-static inline void igemm_config(long long M, int Nout, int srcC, int* mode, int* BM, int* BN) {
+static inline void igemm_config(long long M, int Nout, int srcC, int taps, int* mode, int* BM, int* BN) {
   const bool narrow = Nout <= 64;
-  if (srcC % 64 == 0 && M >= g_dma_min_rows) {
+  if (srcC % 64 == 0 && taps <= 32 && M >= g_dma_min_rows) {
     *mode = 1; *BM = 256; *BN = narrow ? 64 : 128;
   } else {
     *mode = 0; *BM = narrow ? 256 : 128; *BN = narrow ? 64 : 128;
@@ -508,7 +535,7 @@ static inline void igemm_config(long long M, int Nout, int srcC, int* mode, int*
 
 static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   int mode, BM, BN;
-  igemm_config(p.M, p.Nout, p.sC, &mode, &BM, &BN);
+  igemm_config(p.M, p.Nout, p.sC, p.R * p.S, &mode, &BM, &BN);
   const bool narrow = BN == 64;
   p.ntn = ceil_div(p.Nout, BN);
   const int gm = ceil_div(p.M, BM);
@@ -552,9 +579,9 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
 }
 
 // Number of row tiles (= rows of the BatchNorm partial-sum buffer) mpr_conv_fwd will use.
-int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C) {
+int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S) {
   int mode, BM, BN;
-  igemm_config((long long)B * P * Q, K, C, &mode, &BM, &BN);
+  igemm_config((long long)B * P * Q, K, C, R * S, &mode, &BM, &BN);
   return ceil_div(B * P * Q, BM);
 }
 
@@ -571,6 +598,8 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
   ConvGemmParams p;
   p.src = (const bf16_t*)x; p.wpk = (const bf16_t*)w_fwd; p.dst = (bf16_t*)y; p.add = nullptr; p.stats = stats;
   p.sH = H; p.sW = W; p.sC = C;
+  p.src_bytes = (unsigned)((size_t)B * H * W * C * 2);
+  p.wpk_bytes = (unsigned)((size_t)pad_to(K, 128) * pad_to(R * S * C, 64) * 2);
   p.M = B * P * Q; p.Nout = K; p.Kg = R * S * C; p.Kgpad = pad_to(p.Kg, 64); p.nk = p.Kgpad / 64;
   p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
   p.Pm = P; p.Qm = Q; p.div_pq = make_fastdiv(P * Q); p.div_q = make_fastdiv(Q);
@@ -591,6 +620,8 @@ int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* ad
   p.src = (const bf16_t*)dy; p.wpk = (const bf16_t*)w_dgrad; p.dst = (bf16_t*)dx; p.add = (const bf16_t*)add;
   p.stats = nullptr;
   p.sH = P; p.sW = Q; p.sC = K;
+  p.src_bytes = (unsigned)((size_t)B * P * Q * K * 2);
+  p.wpk_bytes = (unsigned)((size_t)pad_to(C, 128) * pad_to(R * S * K, 64) * 2);
   p.M = B * H * W; p.Nout = C; p.Kg = R * S * K; p.Kgpad = pad_to(p.Kg, 64); p.nk = p.Kgpad / 64;
   p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
   p.Pm = H; p.Qm = W; p.div_pq = make_fastdiv(H * W); p.div_q = make_fastdiv(W);

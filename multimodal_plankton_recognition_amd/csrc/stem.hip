@@ -137,9 +137,88 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ResNet stem (1 input channel, 7x7, stride 2, pad 3) as a space-to-depth problem: the stride-2 7x7 filter on
+// 1 channel equals a stride-1 4x4 filter on the 4 phase channels of the 2x2-decimated image (filter padded to
+// 8x8 with a zero first row/column).  Padding the phases to 8 channels makes it a plain MFMA implicit GEMM
+// (K = 4*4*8 = 128) for the generic conv / wgrad kernels, and the halo is materialised as zeros so that the
+// conv runs with pad 0:  xs[b][i][j][2*dy+dx] = x[b][2*(i-2)+dy][2*(j-2)+dx],  i in [0, H/2+3).
+__global__ __launch_bounds__(256) void stem_s2d_kernel(const float* __restrict__ x, bf16_t* __restrict__ xs, int B,
+                                                       int H, int W) {
+  const int H2 = H / 2 + 3, W2 = W / 2 + 3;
+  const long long total = (long long)B * H2 * W2;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+    const unsigned u = (unsigned)v;
+    const int j = u % W2;
+    const unsigned t = u / W2;
+    const int i = t % H2;
+    const int b = t / H2;
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int r0 = 2 * (i - 2), c0 = 2 * (j - 2);
+    if (r0 >= 0 && r0 < H && c0 >= 0 && c0 < W) {
+      const float2 a = *reinterpret_cast<const float2*>(x + ((size_t)b * H + r0) * W + c0);
+      const float2 c = *reinterpret_cast<const float2*>(x + ((size_t)b * H + r0 + 1) * W + c0);
+      f[0] = a.x; f[1] = a.y; f[2] = c.x; f[3] = c.y;
+    }
+    reinterpret_cast<uint4*>(xs)[v] = pack8(f);
+  }
+}
+
+// w [K][1][7][7] -> w2 [K][8][4][4]:  w2[k][2*dy+dx][r2][s2] = w[k][2*r2+dy-1][2*s2+dx-1]  (0 outside / ch >= 4)
+__global__ void stem_w_s2d_kernel(const float* __restrict__ w, float* __restrict__ w2, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * 128) return;
+  const int s2 = i & 3, r2 = (i >> 2) & 3, c = (i >> 4) & 7, k = i >> 7;
+  float v = 0.f;
+  if (c < 4) {
+    const int r = 2 * r2 + (c >> 1) - 1, s = 2 * s2 + (c & 1) - 1;
+    if (r >= 0 && s >= 0) v = w[(k * 7 + r) * 7 + s];
+  }
+  w2[i] = v;
+}
+
+// dw [K][1][7][7] (+)= gather of dw2 [K][8][4][4]
+__global__ void stem_dw_gather_kernel(const float* __restrict__ dw2, float* __restrict__ dw, int K, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * 49) return;
+  const int s = i % 7, r = (i / 7) % 7, k = i / 49;
+  const int r2 = (r + 1) >> 1, dy = (r + 1) & 1, s2 = (s + 1) >> 1, dx = (s + 1) & 1;
+  const float v = dw2[((k * 8 + 2 * dy + dx) * 4 + r2) * 4 + s2];
+  dw[i] = accumulate ? dw[i] + v : v;
+}
+
 static inline int stem_block(int K) { return (256 / (K / 8)) * (K / 8); }
 
 extern "C" {
+
+// xs [B][H/2+3][W/2+3][8] bf16 <- x [B][H][W] fp32 (1 channel; H, W even)
+int mpr_stem_s2d(const float* x, void* xs, int B, int H, int W, void* stream) {
+  MPR_REQUIRE(x && xs, "mpr_stem_s2d: null pointer");
+  MPR_REQUIRE(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, "mpr_stem_s2d: H and W must be even (got %d x %d)", H, W);
+  const long long total = (long long)B * (H / 2 + 3) * (W / 2 + 3);
+  MPR_REQUIRE(total * 8 < (1ll << 31), "mpr_stem_s2d: tensor exceeds 2^31 elements");
+  long long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  stem_s2d_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)xs, B, H, W);
+  MPR_LAUNCH_CHECK("stem_s2d_kernel");
+  return MPR_OK;
+}
+
+// w2 [K][8][4][4] fp32 <- w [K][1][7][7] fp32
+int mpr_stem_w_s2d(const float* w, float* w2, int K, void* stream) {
+  MPR_REQUIRE(w && w2 && K > 0, "mpr_stem_w_s2d: bad arguments");
+  stem_w_s2d_kernel<<<ceil_div(K * 128, 256), 256, 0, (hipStream_t)stream>>>(w, w2, K);
+  MPR_LAUNCH_CHECK("stem_w_s2d_kernel");
+  return MPR_OK;
+}
+
+// dw [K][1][7][7] fp32 (+)= dw2 [K][8][4][4] fp32
+int mpr_stem_dw_gather(const float* dw2, float* dw, int K, int accumulate, void* stream) {
+  MPR_REQUIRE(dw2 && dw && K > 0, "mpr_stem_dw_gather: bad arguments");
+  stem_dw_gather_kernel<<<ceil_div(K * 49, 256), 256, 0, (hipStream_t)stream>>>(dw2, dw, K, accumulate);
+  MPR_LAUNCH_CHECK("stem_dw_gather_kernel");
+  return MPR_OK;
+}
 
 int mpr_stem_fwd_stat_rows(int B, int P, int Q, int K) {
   const int ppb = stem_block(K) / (K / 8);

@@ -73,12 +73,20 @@ class StemFn(torch.autograd.Function):
     def forward(ctx, x, conv_w, bn_w, bn_b, mod):
         g = mod.geom
         train = mod.training
-        y, stats = ops.stem_fwd(x, conv_w, g, train)
+        # ResNet stem (1 channel, 7x7/2, pad 3, even image): space-to-depth -> MFMA implicit GEMM
+        s2d = (x.dim() == 4 and g.C == 1 and g.R == 7 and g.S == 7 and g.sh == 2 and g.ph == 3
+               and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and g.K % 8 == 0)
+        if s2d:
+            x, g2, wf2 = ops.stem_s2d_operands(x, conv_w)
+            y, stats = ops.conv_fwd(x, wf2, g2, train)
+            g = g2
+        else:
+            y, stats = ops.stem_fwd(x, conv_w, g, train)
         st = _bn_coefs(stats, _rows(y), mod.bn1, train)
         pooled, idx = ops.bn_relu_maxpool_fwd(y, st)
         if train:
             ctx.save_for_backward(x, y, idx, conv_w, bn_w)
-            ctx.st, ctx.g = st, g
+            ctx.st, ctx.g, ctx.s2d = st, g, s2d
         ctx.train = train
         return pooled
 
@@ -89,7 +97,10 @@ class StemFn(torch.autograd.Function):
         x, y, idx, conv_w, bn_w = ctx.saved_tensors
         da = ops.maxpool_bwd(dpooled.contiguous(), idx, y.shape)
         dx, dgamma, dbeta, _ = ops.bn_bwd(da, None, y, bn_w, ctx.st, MASK_RECOMPUTE)
-        dw = ops.stem_wgrad(x, dx, ctx.g, conv_w.shape)
+        if ctx.s2d:
+            dw = ops.stem_s2d_wgrad(x, dx, ctx.g, conv_w.shape)
+        else:
+            dw = ops.stem_wgrad(x, dx, ctx.g, conv_w.shape)
         return None, dw, dgamma, dbeta, None
 
 

@@ -71,7 +71,7 @@ def conv_fwd(x, wf, g, want_stats):
     y = torch.empty(_like_spatial(x, B, P, Q, g.K), dtype=BF16, device=x.device)
     stats = None
     if want_stats:
-        rows = N.query('mpr_conv_fwd_stat_rows', B, P, Q, g.K, C)
+        rows = N.query('mpr_conv_fwd_stat_rows', B, P, Q, g.K, C, g.R, g.S)
         stats = torch.empty(rows, 2, g.K, dtype=F32, device=x.device)
     N.call('mpr_conv_fwd', x, wf, y, stats, B, H, W, C, g.K, *g.tail)
     return y, stats
@@ -103,6 +103,32 @@ def stem_fwd(x, weight, g, want_stats):
         stats = torch.empty(rows, 2, g.K, dtype=F32, device=x.device)
     N.call('mpr_stem_fwd', x, weight.detach(), y, stats, B, H, W, C, g.K, *g.tail)
     return y, stats
+
+
+def stem_s2d_operands(x, weight):
+    """ResNet stem as space-to-depth (csrc/stem.hip): x fp32 [B,H,W,1] -> xs bf16 [B,H/2+3,W/2+3,8];
+    weight [K,1,7,7] -> packed panel of the equivalent [K,8,4,4] stride-1 pad-0 filter (cached)."""
+    B, H, W, _ = x.shape
+    K = weight.shape[0]
+    xs = torch.empty(B, H // 2 + 3, W // 2 + 3, 8, dtype=BF16, device=x.device)
+    N.call('mpr_stem_s2d', x, xs, B, H, W)
+    g2 = ConvGeom((K, 8, 4, 4), 1, 0)
+    key = (weight.data_ptr(), weight._version)
+    hit = getattr(weight, '_mpr_s2d', None)
+    if hit is None or hit[0] != key:
+        w2 = torch.empty(K, 8, 4, 4, dtype=F32, device=x.device)
+        N.call('mpr_stem_w_s2d', weight.detach(), w2, K)
+        wf2, _ = packed_weights(w2, g2, need_dgrad=False)
+        weight._mpr_s2d = (key, wf2)
+        hit = weight._mpr_s2d
+    return xs, g2, hit[1]
+
+
+def stem_s2d_wgrad(xs, dy, g2, weight_shape):
+    dw2 = conv_wgrad(xs, dy, g2, (g2.K, 8, 4, 4))
+    dw = torch.empty(weight_shape, dtype=F32, device=xs.device)
+    N.call('mpr_stem_dw_gather', dw2, dw, g2.K, 0)
+    return dw
 
 
 def stem_wgrad(x, dy, g, weight_shape):

@@ -39,7 +39,7 @@ def _basic_block_2d(sd, p, x, stride, train):
 
 def resnet_features(sd, image, blocks=(2, 2, 2, 2), train=False, prefix=''):
     """ResNet BasicBlock backbone, pooled features [B, 512]."""
-    x = r(F.conv2d(image, sd[prefix + 'conv1.weight'], None, 2, 3))     # stem: fp32 operands
+    x = r(F.conv2d(r(image), r(sd[prefix + 'conv1.weight']), None, 2, 3))
     x = r(F.relu(_bn2d(sd, prefix + 'bn1', x, train)))
     x = F.max_pool2d(x, 3, 2, 1)
     for li, reps in enumerate(blocks, start=1):
