@@ -68,6 +68,8 @@ int mpr_stem_wgrad(const float* x, const void* dy, float* dw_oihw, int accumulat
 /* ---- BatchNorm, train and eval (nn.BatchNorm1d/2d defaults: src/profile_encoder.py:126,129,168) */
 int mpr_bn_reduce_rows(long long rows, int C);
 int mpr_bn_stats(const void* x, float* partials, long long rows, int C, void* stream);
+int mpr_bn_reduce_partials(const float* partials, int nparts, float* out /* [nsplit][2][C] */, int nsplit, int C,
+                           void* stream);
 int mpr_bn_finalize_stats(const float* partials, int nparts, long long count, const float* gamma, const float* beta,
                           float* running_mean /* may be NULL */, float* running_var, float momentum, float eps,
                           float* scale, float* shift, float* mean, float* invstd, int C, void* stream);

@@ -47,6 +47,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_stats_kernel(
   }
 }
 
+// Pre-reduction of long partial lists (the stem conv at batch 512 leaves 25088 rows): [nparts][2][C] ->
+// [nsplit][2][C], slice s sums rows s, s+nsplit, ...; spreads the read over many CUs instead of C/32 blocks.
+__global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __restrict__ partials, int nparts,
+                                                                 float* __restrict__ out, int nsplit, int C2) {
+  __shared__ double red[8][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5, s = blockIdx.y;
+  double a = 0.0;
+  if (c < C2)
+    for (int i = s + pl * nsplit; i < nparts; i += 8 * nsplit) a += (double)partials[(size_t)i * C2 + c];
+  red[pl][threadIdx.x & 31] = a;
+  __syncthreads();
+  if (pl == 0 && c < C2) {
+    for (int i = 1; i < 8; ++i) a += red[i][threadIdx.x];
+    out[(size_t)s * C2 + c] = (float)a;
+  }
+}
+
 // eval-mode coefficients from the running statistics
 __global__ void bn_eval_coefs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
@@ -255,6 +272,15 @@ int mpr_bn_stats(const void* x, float* partials, long long rows, int C, void* st
   const int block = cg_block(C / 8);
   bn_stats_kernel<<<ew_grid(nvec, block), block, 0, (hipStream_t)stream>>>((const bf16_t*)x, partials, nvec, C);
   MPR_LAUNCH_CHECK("bn_stats_kernel");
+  return MPR_OK;
+}
+
+// out [nsplit][2][C] <- partials [nparts][2][C]   (use when nparts is in the thousands)
+int mpr_bn_reduce_partials(const float* partials, int nparts, float* out, int nsplit, int C, void* stream) {
+  MPR_REQUIRE(partials && out && nsplit > 0 && nsplit <= nparts, "mpr_bn_reduce_partials: bad arguments");
+  bn_reduce_partials_kernel<<<dim3(ceil_div(2 * C, 32), nsplit), 256, 0, (hipStream_t)stream>>>(partials, nparts, out,
+                                                                                               nsplit, 2 * C);
+  MPR_LAUNCH_CHECK("bn_reduce_partials_kernel");
   return MPR_OK;
 }
 

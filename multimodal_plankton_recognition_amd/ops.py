@@ -139,6 +139,16 @@ def stem_wgrad(x, dy, g, weight_shape):
 
 
 # ------------------------------------------------------------------------------------------ batch norm
+def _prereduce(parts):
+    """Long per-workgroup partial lists are folded to 64 rows first (spreads the read over the chip)."""
+    n, _, C = parts.shape
+    if n <= 512:
+        return parts
+    out = torch.empty(64, 2, C, dtype=F32, device=parts.device)
+    N.call('mpr_bn_reduce_partials', parts, n, out, 64, C)
+    return out
+
+
 class BNState:
     """Per-call BatchNorm coefficients: scale/shift always, mean/invstd in train mode."""
     __slots__ = ('scale', 'shift', 'mean', 'invstd')
@@ -158,6 +168,7 @@ def bn_coefs(stats, count, bn, train, x=None):
             N.call('mpr_bn_stats', x, stats, rows, C)
         st.mean = torch.empty(C, dtype=F32, device=dev)
         st.invstd = torch.empty(C, dtype=F32, device=dev)
+        stats = _prereduce(stats)
         N.call('mpr_bn_finalize_stats', stats, stats.shape[0], count, bn.weight.detach(), bn.bias.detach(),
                bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps), st.scale, st.shift,
                st.mean, st.invstd, C)
@@ -185,6 +196,7 @@ def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False):
     dev = x.device
     parts = torch.empty(N.query('mpr_bn_reduce_rows', rows, C), 2, C, dtype=F32, device=dev)
     N.call('mpr_bn_bwd_reduce', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, rows, C)
+    parts = _prereduce(parts)
     dgamma = torch.empty(C, dtype=F32, device=dev)
     dbeta = torch.empty(C, dtype=F32, device=dev)
     coef = torch.empty(3, C, dtype=F32, device=dev)
@@ -311,19 +323,28 @@ class FusedSGD:
         self.steps = 0
         self._table_key = None
         self._table = None
-        self._grads = None
+        self._pinned = None
+        self._table_dev = None
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             p.grad = None
 
     def _build_table(self, live):
-        rows = []
-        for p in live:
+        # pinned staging + device table are allocated once (also keeps the upload legal inside a HIP-graph
+        # capture, where allocating pinned memory is not)
+        if self._pinned is None:
+            self._pinned = torch.empty(len(self.params), 4, dtype=torch.int64).pin_memory()
+            self._table_dev = torch.empty(len(self.params), 4, dtype=torch.int64, device=live[0].device)
+        for i, p in enumerate(live):
             if id(p) not in self.bufs:
                 self.bufs[id(p)] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            rows.append([p.data_ptr(), p.grad.data_ptr(), self.bufs[id(p)].data_ptr(), p.numel()])
-        return torch.tensor(rows, dtype=torch.int64).pin_memory().to(live[0].device, non_blocking=True)
+            self._pinned[i, 0] = p.data_ptr()
+            self._pinned[i, 1] = p.grad.data_ptr()
+            self._pinned[i, 2] = self.bufs[id(p)].data_ptr()
+            self._pinned[i, 3] = p.numel()
+        self._table_dev[:len(live)].copy_(self._pinned[:len(live)], non_blocking=True)
+        return self._table_dev
 
     @torch.no_grad()
     def step(self):
