@@ -1,0 +1,153 @@
+"""Minimal stand-in for the slice of ``lightning`` the reference's scripts use
+(scripts/train_multi.py:86-107): Trainer.fit with gradient accumulation, per-epoch validation,
+ModelCheckpoint (top-k by a monitored metric, Lightning's ``{epoch}_{valid_loss:.5f}`` naming and
+``state_dict`` / ``hyper_parameters`` checkpoint keys), EarlyStopping, and a logger that writes
+``<save_dir>/<name>/version_N/metrics.jsonl`` where TensorBoardLogger would write event files.
+``lightning`` itself is not installed in this image.
+"""
+import json
+import math
+import os
+import re
+
+import torch
+
+
+class TensorBoardLogger:
+    """Directory layout of lightning's TensorBoardLogger; metrics go to metrics.jsonl (tensorboard is absent)."""
+
+    def __init__(self, save_dir, name):
+        root = os.path.join(save_dir, name)
+        os.makedirs(root, exist_ok=True)
+        versions = [int(m.group(1)) for d in os.listdir(root) if (m := re.fullmatch(r'version_(\d+)', d))]
+        self.version = max(versions) + 1 if versions else 0
+        self.log_dir = os.path.join(root, f'version_{self.version}')
+        os.makedirs(self.log_dir, exist_ok=True)
+
+    def log_metrics(self, metrics):
+        with open(os.path.join(self.log_dir, 'metrics.jsonl'), 'a') as f:
+            f.write(json.dumps(metrics) + '\n')
+
+
+class ModelCheckpoint:
+    def __init__(self, filename='{epoch}', monitor='valid_loss', save_top_k=1, mode='min'):
+        self.filename, self.monitor, self.save_top_k, self.mode = filename, monitor, save_top_k, mode
+        self.best = []          # [(score, path)]
+
+    def format_name(self, epoch, metrics):
+        # lightning renders "{epoch}_{valid_loss:.5f}" as "epoch=86_valid_loss=0.92302"
+        def sub(m):
+            key, fmt = m.group(1), m.group(2) or ''
+            val = epoch if key == 'epoch' else metrics[key]
+            return f'{key}=' + format(val, fmt[1:] if fmt else '')
+        return re.sub(r'\{(\w+)(:[^}]*)?\}', sub, self.filename) + '.ckpt'
+
+    def on_validation_end(self, trainer, model, metrics):
+        if self.monitor not in metrics or self.save_top_k == 0:
+            return
+        score = float(metrics[self.monitor])
+        sign = 1.0 if self.mode == 'min' else -1.0
+        worst = max(self.best, key=lambda t: sign * t[0]) if self.best else None
+        if self.save_top_k > 0 and len(self.best) >= self.save_top_k and sign * score >= sign * worst[0]:
+            return
+        ckpt_dir = os.path.join(trainer.logger.log_dir, 'checkpoints')
+        os.makedirs(ckpt_dir, exist_ok=True)
+        path = os.path.join(ckpt_dir, self.format_name(trainer.current_epoch, metrics))
+        torch.save({'state_dict': model.state_dict(), 'hyper_parameters': getattr(model, 'hparams', {}),
+                    'epoch': trainer.current_epoch, 'global_step': trainer.global_step,
+                    'optimizer_states': [trainer.optimizer.state_dict()] if trainer.optimizer else []}, path)
+        self.best.append((score, path))
+        if self.save_top_k > 0 and len(self.best) > self.save_top_k:
+            drop = max(self.best, key=lambda t: sign * t[0])
+            self.best.remove(drop)
+            if os.path.exists(drop[1]):
+                os.remove(drop[1])
+
+
+class EarlyStopping:
+    def __init__(self, monitor='valid_loss', min_delta=0.0, patience=3, check_finite=True, mode='min'):
+        self.monitor, self.min_delta, self.patience, self.check_finite, self.mode = monitor, min_delta, patience, check_finite, mode
+        self.best, self.wait = None, 0
+
+    def on_validation_end(self, trainer, model, metrics):
+        if self.monitor not in metrics:
+            return
+        score = float(metrics[self.monitor])
+        if self.check_finite and not math.isfinite(score):
+            trainer.should_stop = True
+            return
+        sign = 1.0 if self.mode == 'min' else -1.0
+        if self.best is None or sign * score < sign * self.best - self.min_delta:
+            self.best, self.wait = score, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                trainer.should_stop = True
+
+
+def load_from_checkpoint(model_cls, path, map_location='cpu', **override):
+    """LightningModule.load_from_checkpoint: rebuild from saved hyper-parameters, then load the weights."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    model = model_cls(**{**ckpt['hyper_parameters'], **override})
+    model.load_state_dict(ckpt['state_dict'])
+    return model
+
+
+class Trainer:
+    def __init__(self, logger=None, callbacks=(), max_epochs=1000, min_epochs=0, accumulate_grad_batches=1,
+                 precision=None, val_check_interval=None, check_val_every_n_epoch=1, log_every_n_steps=50,
+                 max_steps=-1, limit_train_batches=None, limit_val_batches=None, device=None, **unused):
+        self.logger, self.callbacks = logger, list(callbacks)
+        self.max_epochs, self.min_epochs = max_epochs, min_epochs or 0
+        self.accumulate = max(1, int(accumulate_grad_batches or 1))
+        self.check_val_every_n_epoch = check_val_every_n_epoch or 1
+        self.max_steps = max_steps
+        self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
+        self.precision = precision            # compute precision is fixed by the kernels (bf16 storage, fp32 accumulate)
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.current_epoch, self.global_step, self.should_stop = 0, 0, False
+        self.optimizer = None
+        self.callback_metrics = {}
+
+    def log(self, metrics):
+        self.callback_metrics.update(metrics)
+        if self.logger is not None:
+            self.logger.log_metrics(metrics)
+
+    def _to_device(self, batch):
+        return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def fit(self, model, train_loader, valid_loader=None):
+        model.trainer = self
+        model.to(self.device)
+        self.optimizer = model.configure_optimizers()
+        for epoch in range(self.max_epochs):
+            self.current_epoch = epoch
+            model.train()
+            self.optimizer.zero_grad()
+            for i, batch in enumerate(train_loader):
+                if self.limit_train_batches is not None and i >= self.limit_train_batches:
+                    break
+                loss = model.training_step(self._to_device(batch), i)
+                (loss / self.accumulate if self.accumulate > 1 else loss).backward()
+                if (i + 1) % self.accumulate == 0:
+                    self.optimizer.step()
+                    self.optimizer.zero_grad()
+                    self.global_step += 1
+                    if 0 < self.max_steps <= self.global_step:
+                        self.should_stop = True
+                        break
+            model.on_train_epoch_end()
+            if valid_loader is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
+                model.eval()
+                with torch.no_grad():
+                    for i, batch in enumerate(valid_loader):
+                        if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                            break
+                        model.validation_step(self._to_device(batch), i)
+                model.on_validation_epoch_end()
+                for cb in self.callbacks:
+                    cb.on_validation_end(self, model, self.callback_metrics)
+            if self.should_stop and epoch + 1 >= self.min_epochs:
+                break
+        return model

@@ -1,0 +1,120 @@
+"""GPU: the reference's entry surfaces end to end -- scripts/train_multi.py (CLI, YAML card, run naming, Lightning-style
+checkpoints) on synthetic data, checkpoint reload, and the single-modality classifiers (configs C1/C2: encoder + fc + CE +
+argmax class indices)."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_multi_script_runs_and_checkpoints(tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, 'train_multi.py', '-m', '../model_cards/smoke_multi.yaml', '--synthetic', '64',
+           '--max-epochs', '2', '--logdir', str(tmp_path)]
+    out = subprocess.run(cmd, cwd=os.path.join(ROOT, 'scripts'), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'Training from model card ../model_cards/smoke_multi.yaml' in out.stdout
+    run = os.path.join(str(tmp_path), 'smoke_multi_synthetic_data', 'version_0')
+    lines = [json.loads(l) for l in open(os.path.join(run, 'metrics.jsonl'))]
+    assert any('train_loss' in l for l in lines) and any('valid_loss' in l for l in lines)
+    assert all(np.isfinite(l.get('valid_loss', 0.0)) for l in lines)
+    ckpts = glob.glob(os.path.join(run, 'checkpoints', 'epoch=*_valid_loss=*.ckpt'))
+    assert 1 <= len(ckpts) <= 2
+    # reload as experiments.ipynb does (MultiModel.load_from_checkpoint) and run the predict path
+    from multimodal_plankton_recognition_amd.model import MultiModel
+    from multimodal_plankton_recognition_amd.trainer import load_from_checkpoint
+    model = load_from_checkpoint(MultiModel, ckpts[0]).to('cuda').eval()
+    g = torch.Generator().manual_seed(0)
+    batch = {'image': torch.rand(4, 1, 64, 64, generator=g).cuda() * 2 - 1, 'profile': torch.rand(4, 64, 6, generator=g).cuda(),
+             'image_shape': torch.randint(32, 400, (4, 2), generator=g).cuda(),
+             'profile_len': torch.randint(8, 1024, (4, 1), generator=g).cuda(), 'buckets': 1, 'label': list('abcd')}
+    with torch.no_grad():
+        out = model.predict_step(batch, 0)
+    assert out['image_emb'].shape == (4, 64) and torch.isfinite(out['image_emb']).all() and out['label'] == list('abcd')
+
+
+@pytest.mark.parametrize('kind', ['image', 'profile'])
+def test_classifier_step_and_class_indices(kind):
+    """ImageModel / ProfileModel (src/model.py:151-451): logits -> CE -> argmax.  The fc / CE / argmax stage is exact
+    fp32: checked against torch on the SAME features; indices must be identical."""
+    from multimodal_plankton_recognition_amd.model import ImageModel, ProfileModel
+    torch.manual_seed(0)
+    names = [f'c{i}' for i in range(7)]
+    optim = dict(lr=1e-2, momentum=0.9, weight_decay=1e-3, nesterov=True)
+    g = torch.Generator().manual_seed(1)
+    B = 12
+    if kind == 'image':
+        model = ImageModel(dict(name='resnet18', dropout=0.0), optim, names)
+        batch = {'image': (torch.randn(B, 1, 64, 64, generator=g) * 0.3).clamp(-1, 1),
+                 'image_shape': torch.randint(32, 400, (B, 2), generator=g)}
+        enc = lambda m, b: m.image_encoder(image=b['image'], image_shape=b['image_shape'])
+    else:
+        model = ProfileModel(dict(dim_in=6, blocks=[1, 1, 1, 1], base_channels=16, dropout=0.0), optim, names)
+        batch = {'profile': torch.rand(B, 96, 6, generator=g) * 2 - 1, 'profile_len': torch.randint(8, 1024, (B, 1), generator=g)}
+        enc = lambda m, b: m.profile_encoder(profile=b['profile'], profile_len=b['profile_len'])
+    batch['label'] = [names[i % 7] for i in range(B)]
+    model.to('cuda').train()
+    dbatch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    opt = model.configure_optimizers()
+    loss = model.training_step(dbatch, 0)
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss) and model.fc.weight.grad is not None
+    model.eval()
+    with torch.no_grad():
+        feats = enc(model, dbatch)
+        out = model.predict_step(dbatch, 0)
+        model.validation_step(dbatch, 0)
+    ref_logits = torch.nn.functional.linear(feats.cpu().double(), model.fc.weight.cpu().double(), model.fc.bias.cpu().double())
+    np.testing.assert_allclose(out['logits'].cpu().numpy(), ref_logits.numpy(), rtol=1e-4, atol=1e-5)
+    assert torch.equal(out['pred'].cpu(), ref_logits.argmax(1))          # bit-exact class indices
+    y = torch.tensor([i % 7 for i in range(B)])
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits.float(), y)
+    assert abs(model.valid_loss[0].item() - ref_loss.item()) < 1e-4
+    model.on_validation_epoch_end()
+    assert 0.0 <= model.logged['valid_acc'] <= 1.0
+
+
+def test_dp_step_world1_equals_single_gpu_step():
+    """DataParallelStep (sharded CLIP + flat all-reduce) at world size 1 must reproduce the plain step."""
+    import torch.distributed as dist
+    from multimodal_plankton_recognition_amd.model import MultiModel
+    from multimodal_plankton_recognition_amd import distributed as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', RANK='0', WORLD_SIZE='1')
+    D.init(torch.device('cuda', 0))
+    try:
+        cfg = dict(dim_embed=64, image_encoder_args=dict(name='resnet18', dropout=0.0),
+                   profile_encoder_args=dict(dim_in=6, blocks=[1, 1, 1, 1], base_channels=16, dropout=0.0),
+                   coordination_args=dict(method='clip'), optim_args=dict(lr=5e-3, momentum=0.9, weight_decay=1e-3, nesterov=True))
+        g = torch.Generator().manual_seed(5)
+        batch = {'image': (torch.randn(16, 1, 64, 64, generator=g) * 0.3).clamp(-1, 1).cuda(),
+                 'profile': (torch.rand(16, 64, 6, generator=g) * 2 - 1).cuda(),
+                 'image_shape': torch.randint(32, 400, (16, 2), generator=g).cuda(),
+                 'profile_len': torch.randint(8, 1024, (16, 1), generator=g).cuda(), 'buckets': 1}
+        results = []
+        for dp in (False, True):
+            torch.manual_seed(3)
+            model = MultiModel(**cfg).cuda().train()
+            opt = model.configure_optimizers()
+            if dp:
+                loss = D.DataParallelStep(model, opt, 1).step(batch)
+            else:
+                opt.zero_grad()
+                loss = model.training_step(batch, 0)
+                loss.backward()
+                opt.step()
+            results.append((loss.item(), {k: v.detach().clone() for k, v in model.state_dict().items()}))
+        assert abs(results[0][0] - results[1][0]) < 1e-5
+        for k, v in results[0][1].items():
+            if v.is_floating_point():
+                assert torch.allclose(v, results[1][1][k], rtol=1e-4, atol=1e-6), k
+    finally:
+        D.shutdown()
