@@ -73,7 +73,7 @@ def test_classifier_step_and_class_indices(kind):
         feats = enc(model, dbatch)
         out = model.predict_step(dbatch, 0)
         model.validation_step(dbatch, 0)
-    ref_logits = torch.nn.functional.linear(feats.cpu().double(), model.fc.weight.cpu().double(), model.fc.bias.cpu().double())
+    ref_logits = torch.nn.functional.linear(feats.cpu().double(), model.fc.weight.detach().cpu().double(), model.fc.bias.detach().cpu().double())
     np.testing.assert_allclose(out['logits'].cpu().numpy(), ref_logits.numpy(), rtol=1e-4, atol=1e-5)
     assert torch.equal(out['pred'].cpu(), ref_logits.argmax(1))          # bit-exact class indices
     y = torch.tensor([i % 7 for i in range(B)])
