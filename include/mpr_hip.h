@@ -44,6 +44,10 @@ int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S);
 /* rows (B*P*Q) from which the LDS-DMA ring kernel replaces the register-staged one (default 16384);
  * returns the previous threshold */
 int mpr_conv_set_dma_min_rows(int rows);
+/* tile / ring-depth variant of the LDS-DMA kernel (tuning knob, see conv_igemm.hip; default 0, 0) */
+int mpr_conv_set_variant(int narrow, int wide);
+/* output pixels (B*P*Q) from which the LDS-DMA weight-gradient kernel is used (default 16384) */
+int mpr_conv_set_wgrad_dma_min_pixels(int pixels);
 int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may be NULL */, int B, int H, int W,
                  int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
 int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add /* may be NULL */, int B, int H,

@@ -26,6 +26,7 @@ struct ConvGemmParams {
   float* stats;        // optional [gridM][2][Nout]
   int sH, sW, sC;
   unsigned src_bytes, wpk_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
+  unsigned rowpat;                 // sum_r 1 << (r*S): one bit per filter row (tap masks of the LDS-DMA kernel)
   int M, Nout, Kg, Kgpad, nk, ntn;
   int R, S, sh, sw, ph, pw;
   FastDiv div_pq, div_q;   // row m -> (b, p, q)
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   static_assert(A_IT % 2 == 0 && B_IT % 2 == 0, "instruction parity must follow the local index");
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int CS_STRIDE = BN * 4 + 16;
-  static_assert(STAGES * STAGE >= BM * CS_STRIDE, "epilogue tile must fit the ring");
+  // (the host sizes the dynamic LDS as max(ring, epilogue tile))
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -289,21 +290,42 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
       const int lc = lc_even ^ ((j & 1) << 2);
       voff[j] = (uint32_t)(b * p.sH * p.sW) * (uint32_t)(2 * p.sC) + (uint32_t)(rh * (DGRAD ? -tstep_h : tstep_h)) +
                 (uint32_t)(rw * (DGRAD ? -tstep_w : tstep_w)) + (uint32_t)(lc * 16);
+      // tap (r, s) is valid iff row-tap r and column-tap s are both valid (the conditions are per axis):
+      // S column bits are built once and replicated for every valid row tap
       uint32_t mk = 0;
-      for (int r = 0, t = 0; r < p.R; ++r)
-        for (int s2 = 0; s2 < p.S; ++s2, ++t) {
-          bool ok;
-          if (!DGRAD) {
-            ok = (unsigned)(rh + r) < (unsigned)p.sH && (unsigned)(rw + s2) < (unsigned)p.sW;
-          } else {
-            int oh = rh - r, ow = rw - s2;
-            ok = oh >= 0 && ow >= 0;
-            if (p.sh == 2) { ok = ok && !(oh & 1); oh >>= 1; }
-            if (p.sw == 2) { ok = ok && !(ow & 1); ow >>= 1; }
-            ok = ok && oh < p.sH && ow < p.sW;
-          }
-          mk |= (ok ? 1u : 0u) << t;
+      if (!DGRAD) {
+        // valid taps are an index range per axis -> closed-form masks (no loops in the prologue)
+        const int slo = max(0, -rw), shi = min(p.S, p.sW - rw);
+        const int rlo = max(0, -rh), rhi = min(p.R, p.sH - rh);
+        if (shi > slo && rhi > rlo) {
+          const uint32_t cm = ((1u << shi) - 1u) & ~((1u << slo) - 1u);
+          mk = cm * (p.rowpat & ((1u << (rhi * p.S)) - 1u) & ~((1u << (rlo * p.S)) - 1u));
         }
+      } else if (p.sh == 1 && p.sw == 1) {
+        // 0 <= rh - r < sH  <=>  r in [rh - sH + 1, rh]
+        const int slo = max(0, rw - p.sW + 1), shi = min(p.S, rw + 1);
+        const int rlo = max(0, rh - p.sH + 1), rhi = min(p.R, rh + 1);
+        if (shi > slo && rhi > rlo) {
+          const uint32_t cm = ((1u << shi) - 1u) & ~((1u << slo) - 1u);
+          mk = cm * (p.rowpat & ((1u << (rhi * p.S)) - 1u) & ~((1u << (rlo * p.S)) - 1u));
+        }
+      } else {
+        uint32_t cmask = 0;
+        for (int s2 = 0; s2 < p.S; ++s2) {
+          int ow = rw - s2;
+          bool ok = ow >= 0;
+          if (p.sw == 2) { ok = ok && !(ow & 1); ow >>= 1; }
+          ok = ok && ow < p.sW;
+          cmask |= (ok ? 1u : 0u) << s2;
+        }
+        for (int r = 0; r < p.R; ++r) {
+          int oh = rh - r;
+          bool ok = oh >= 0;
+          if (p.sh == 2) { ok = ok && !(oh & 1); oh >>= 1; }
+          ok = ok && oh < p.sH;
+          mk |= (ok ? cmask : 0u) << (r * p.S);
+        }
+      }
       vmask[j] = mk;
     }
   }
@@ -524,19 +546,35 @@ extern "C" int mpr_conv_set_dma_min_rows(int rows) {   // tuning / test knob; re
   return old;
 }
 
+// tile / ring-depth variants of the LDS-DMA kernel (tuning knob; defaults are the measured best)
+//   narrow (N <= 64): 0 = 256x64, 2 stages (2 WG/CU)   1 = 256x64, 3 stages (1 WG/CU)   2 = 128x64, 2 stages (3 WG/CU)
+//   wide   (N > 64) : 0 = 256x128, 3 stages, 8 waves    1 = 128x128, 2 stages (2 WG/CU)   2 = 128x128, 3 stages
+static int g_variant_narrow = 0, g_variant_wide = 1;
+extern "C" int mpr_conv_set_variant(int narrow, int wide) {
+  g_variant_narrow = narrow;
+  g_variant_wide = wide;
+  return 0;
+}
+
 static inline void igemm_config(long long M, int Nout, int srcC, int taps, int* mode, int* BM, int* BN) {
   const bool narrow = Nout <= 64;
   if (srcC % 64 == 0 && taps <= 32 && M >= g_dma_min_rows) {
-    *mode = 1; *BM = 256; *BN = narrow ? 64 : 128;
+    *mode = 1; *BN = narrow ? 64 : 128;
+    *BM = narrow ? (g_variant_narrow == 2 ? 128 : 256) : (g_variant_wide != 0 ? 128 : 256);
   } else {
     *mode = 0; *BM = narrow ? 256 : 128; *BN = narrow ? 64 : 128;
   }
 }
 
 static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
+  p.rowpat = 0;
+  for (int r = 0; r < p.R && r * p.S < 32; ++r) p.rowpat |= 1u << (r * p.S);
   int mode, BM, BN;
   igemm_config(p.M, p.Nout, p.sC, p.R * p.S, &mode, &BM, &BN);
   const bool narrow = BN == 64;
+  // stride-2 data gradients (3/4 of the taps are holes) run better on the deep 256x128 ring
+  const bool s2dgrad = dgrad && mode == 1 && !narrow && (p.sh == 2 || p.sw == 2);
+  if (s2dgrad) BM = 256;
   p.ntn = ceil_div(p.Nout, BN);
   const int gm = ceil_div(p.M, BM);
   dim3 grid(gm * p.ntn);
@@ -550,11 +588,21 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_set = true;                                                                                \
     }                                                                                                 \
+    const size_t ring_ = (size_t)ST_ * (64 * WM_ + 64 * WN_) * 128;                                   \
+    const size_t epi_ = (size_t)(64 * WM_) * (64 * WN_ * 4 + 16);                                     \
     conv_igemm_dma_kernel<WM_, WN_, ST_, DG_>                                                         \
-        <<<grid, 64 * WM_ * WN_, (size_t)ST_ * (64 * WM_ + 64 * WN_) * 128, st>>>(p);                 \
+        <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                               \
   } while (0)
-    if (narrow) { if (dgrad) MPR_DMA(4, 1, 2, true); else MPR_DMA(4, 1, 2, false); }
-    else        { if (dgrad) MPR_DMA(4, 2, 3, true); else MPR_DMA(4, 2, 3, false); }
+    if (narrow) {
+      if (g_variant_narrow == 1)      { if (dgrad) MPR_DMA(4, 1, 3, true); else MPR_DMA(4, 1, 3, false); }
+      else if (g_variant_narrow == 2) { if (dgrad) MPR_DMA(2, 1, 2, true); else MPR_DMA(2, 1, 2, false); }
+      else                            { if (dgrad) MPR_DMA(4, 1, 2, true); else MPR_DMA(4, 1, 2, false); }
+    } else {
+      if (s2dgrad)                  { MPR_DMA(4, 2, 3, true); }
+      else if (g_variant_wide == 1) { if (dgrad) MPR_DMA(2, 2, 2, true); else MPR_DMA(2, 2, 2, false); }
+      else if (g_variant_wide == 2) { if (dgrad) MPR_DMA(2, 2, 3, true); else MPR_DMA(2, 2, 3, false); }
+      else                          { if (dgrad) MPR_DMA(4, 2, 3, true); else MPR_DMA(4, 2, 3, false); }
+    }
 #undef MPR_DMA
   } else {
     const size_t stage2 = (size_t)2 * (BM + BN) * 128, epi = (size_t)BM * (BN * 4 + 16);

@@ -15,7 +15,9 @@ struct WgradParams {
   const bf16_t* dy;
   float* dw;
   int H, W, C, K, P, Q, R, S, sh, sw, ph, pw;
-  int Mpix, Ng, cps, ntm, ntn;
+  unsigned x_bytes, dy_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
+  int Mpix, Ng, cps, ntm, ntn, ngroups;
+  unsigned rowpat;              // sum_r 1 << (r*S): one bit per filter row (tap masks of the LDS-DMA kernel)
   FastDiv div_pq, div_q, div_c, div_s;
 };
 
@@ -32,10 +34,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradPar
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  int bid = blockIdx.x;
-  const int nt = bid % p.ntn; bid /= p.ntn;
-  const int mt = bid % p.ntm;
-  const int split = bid / p.ntm;
+  // XCD-aware placement: the ntn column tiles of one (row tile, pixel split) group stream the SAME dy pixels and
+  // overlapping x pixels, so they are put on one XCD (blocks b and b+8 share an XCD) in consecutive slots: the
+  // group's operands then come from HBM once per group instead of once per column tile.  Speed only.
+  const int slot = blockIdx.x >> 3;
+  const int nt = slot % p.ntn;
+  const int grp = (slot / p.ntn) * 8 + (blockIdx.x & 7);
+  if (grp >= p.ngroups) return;
+  const int mt = grp % p.ntm;
+  const int split = grp / p.ntm;
   const int m0 = mt * BM, n0 = nt * BN;
   const int pix_begin = split * p.cps * BKP;
   int pix_end = pix_begin + p.cps * BKP;
@@ -168,6 +175,212 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(const WgradPar
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (C % 64 == 0, K % 64 == 0, <= 31 taps): 64-pixel chunks go global -> LDS with
+// buffer_load_dwordx4 ... lds into a 2-deep ring (one counted wait + one raw barrier per chunk, 16 MFMAs per
+// wave in between).  The DMA image is lane-linear, so rows cannot be padded; the transposing reads are kept
+// conflict-free by XOR-ing the 64-B segment index with a function of the pixel row, applied on the DMA
+// source side and in the read address.  Pixel decoding (b,p,q) -> source offset + per-tap validity bits is
+// done once per pixel per wave (one pixel per lane, in registers); a DMA lane then needs two wave shuffles +
+// 3 VALU: offset = entry.base + lane-constant tap offset, validity = entry.mask & tap bit (invalid lanes get
+// an out-of-range buffer offset -> hardware zero fill).
+template <int N>
+__device__ __forceinline__ void wg_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int CH>   // 64-B segment swizzle for unpadded rows of CH 16-B chunks (row strides 128 / 256 / 384 B)
+__device__ __forceinline__ int wg_seg_xor(int row) {
+  return CH == 16 ? (row & 3) : ((row >> 1) & 1);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WM * WN;
+  constexpr int BM = 64 * WM, BN = 64 * WN, BKP = 64;
+  constexpr int ASTR = BM * 2, BSTR = BN * 2;
+  constexpr int CA = BM / 8, CB = BN / 8;
+  constexpr int A_BYTES = BKP * ASTR, STAGE = BKP * (ASTR + BSTR);
+  constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = BKP * BSTR / 1024;
+  constexpr int A_IT = (A_INSTR + NW - 1) / NW, B_IT = (B_INSTR + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  // XCD-aware placement: the ntn column tiles of one (row tile, pixel split) group stream the SAME dy pixels and
+  // overlapping x pixels, so they are put on one XCD (blocks b and b+8 share an XCD) in consecutive slots: the
+  // group's operands then come from HBM once per group instead of once per column tile.  Speed only.
+  const int slot = blockIdx.x >> 3;
+  const int nt = slot % p.ntn;
+  const int grp = (slot / p.ntn) * 8 + (blockIdx.x & 7);
+  if (grp >= p.ngroups) return;
+  const int mt = grp % p.ntm;
+  const int split = grp / p.ntm;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int pix_begin = split * p.cps * BKP;
+  int pix_end = pix_begin + p.cps * BKP;
+  if (pix_end > p.Mpix) pix_end = p.Mpix;
+  const int nchunks = (pix_end - pix_begin + BKP - 1) / BKP;
+
+  // ---- lane-constant DMA coordinates
+  uint32_t a_off[A_IT];
+  int a_row[A_IT];
+#pragma unroll
+  for (int j = 0; j < A_IT; ++j) {
+    const int q = (wid + j * NW) * 64 + lane;
+    const int row = q / CA, pc = q % CA;
+    const int lc = (((pc >> 2) ^ wg_seg_xor<CA>(row)) << 2) | (pc & 3);
+    a_row[j] = row;
+    a_off[j] = (m0 + lc * 8 < p.K) ? (uint32_t)((row * p.K + m0 + lc * 8) * 2) : 0xFFFFFFF0u;
+  }
+  uint32_t b_off[B_IT], b_bit[B_IT];
+  int b_row[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int q = (wid + j * NW) * 64 + lane;
+    const int row = q / CB, pc = q % CB;
+    const int lc = (((pc >> 2) ^ wg_seg_xor<CB>(row)) << 2) | (pc & 3);
+    const int n = n0 + lc * 8;
+    b_row[j] = row;
+    b_off[j] = 0;
+    b_bit[j] = 0;
+    if (n < p.Ng) {
+      const uint32_t t = fdiv(n, p.div_c);
+      const int c = n - t * p.C;
+      const uint32_t tr = fdiv(t, p.div_s);
+      const int ts = t - tr * p.S;
+      b_off[j] = (uint32_t)((((int)tr * p.W + ts) * p.C + c) * 2);
+      b_bit[j] = 1u << t;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+  // Every wave decodes the chunk's 64 pixels itself, one pixel per lane, and keeps the result in registers;
+  // a DMA lane fetches the entry of ITS pixel row with a wave shuffle (no LDS table: hipcc would fence every
+  // LDS read behind the in-flight LDS-DMA with s_waitcnt vmcnt(0)).
+  uint32_t ex = 0, ey = 0;      // {source byte offset of tap (0,0), tap-validity bits} of pixel (chunk base + lane)
+  auto decode_chunk = [&](int ci) {     // software-pipelined: runs while the previous chunk's DMA is in flight
+    const int pix = pix_begin + ci * BKP + lane;
+    ex = 0;
+    ey = 0;
+    if (pix < pix_end) {
+      const uint32_t b = fdiv(pix, p.div_pq);
+      const uint32_t rem = pix - b * (uint32_t)(p.P * p.Q);
+      const uint32_t pp = fdiv(rem, p.div_q);
+      const uint32_t qq = rem - pp * p.Q;
+      const int ih0 = (int)pp * p.sh - p.ph, iw0 = (int)qq * p.sw - p.pw;
+      ex = (uint32_t)((((int)b * p.H + ih0) * p.W + iw0) * p.C * 2);
+      // valid taps form an index range per axis: columns [slo, shi), rows [rlo, rhi) -> closed-form bit mask
+      const int slo = max(0, -iw0), shi = min(p.S, p.W - iw0);
+      const int rlo = max(0, -ih0), rhi = min(p.R, p.H - ih0);
+      if (shi > slo && rhi > rlo) {
+        const uint32_t cm = ((1u << shi) - 1u) & ~((1u << slo) - 1u);
+        const uint32_t rows = p.rowpat & ((1u << (rhi * p.S)) - 1u) & ~((1u << (rlo * p.S)) - 1u);
+        ey = cm * rows;
+      }
+    }
+  };
+  auto issue_chunk = [&](int ci) {      // uses the (ex, ey) decoded for chunk ci
+    unsigned char* sa = smem + (ci & 1) * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+    const int kb = pix_begin + ci * BKP;
+    const int soff_a = kb * p.K * 2;
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+      const int I = wid + j * NW;
+      if (A_INSTR % NW == 0 || I < A_INSTR) {
+        const uint32_t v = (kb + a_row[j] < pix_end) ? a_off[j] : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(sa + I * 1024), 16, v,
+                                                 soff_a, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int I = wid + j * NW;
+      if (B_INSTR % NW == 0 || I < B_INSTR) {
+        const uint32_t rx = __shfl(ex, b_row[j], 64), ry = __shfl(ey, b_row[j], 64);
+        const uint32_t v = (ry & b_bit[j]) ? rx + b_off[j] : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(sb + I * 1024), 16, v, 0,
+                                                 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // transposing-read lane geometry (see conv_wgrad_kernel); the 64-B segment XOR is lane-constant because the
+  // pixel row of a read is (multiple of 4) + lq
+  const int g16 = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+  uint32_t a_rd[2], b_rd[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int rowl = 8 * (g16 >> 1) + lq;
+    const int inseg = (16 * (g16 & 1) + 4 * lp) * 2;
+    a_rd[t] = rowl * ASTR + (((wm * 2 + t) ^ wg_seg_xor<CA>(lq)) << 6) + inseg;
+    b_rd[t] = A_BYTES + rowl * BSTR + (((wn * 2 + t) ^ wg_seg_xor<CB>(lq)) << 6) + inseg;
+  }
+
+  if (nchunks > 0) {
+    decode_chunk(0);
+    issue_chunk(0);
+    decode_chunk(1);
+  }
+  for (int ci = 0; ci < nchunks; ++ci) {
+    wg_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ci + 1 < nchunks) {
+      issue_chunk(ci + 1);
+      decode_chunk(ci + 2);
+    }
+    const unsigned char* a = smem + (ci & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const unsigned char* pa = a + a_rd[t] + ks * 16 * ASTR;
+        const unsigned char* pb = a + b_rd[t] + ks * 16 * BSTR;
+        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa));
+        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + 4 * ASTR));
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb));
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb + 4 * BSTR));
+        af[t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        bfr[t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const int ln = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + ln;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (k < p.K && n < p.Ng) atomicAdd(p.dw + (size_t)k * p.Ng + n, acc[i][j][e]);
+      }
+    }
+#endif   // __HIP_DEVICE_COMPILE__
+}
+
 // [K][(r,s,c)] fp32 -> OIHW fp32 (optionally accumulating into an existing gradient)
 __global__ void wgrad_unpack_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int C,
                                     int R, int S, int accumulate) {
@@ -182,7 +395,15 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+static int g_wgrad_dma_min_pix = 16384;
+
 extern "C" {
+
+int mpr_conv_set_wgrad_dma_min_pixels(int pixels) {   // tuning / test knob; returns the previous value
+  const int old = g_wgrad_dma_min_pix;
+  g_wgrad_dma_min_pix = pixels;
+  return old;
+}
 
 // dw_oihw[K,C,R,S] (fp32) = sum over the batch;  workspace: K*R*S*C floats (zeroed here).
 int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oihw, int accumulate, int B,
@@ -199,7 +420,54 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   p.H = H; p.W = W; p.C = C; p.K = K; p.P = P; p.Q = Q; p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
   p.Mpix = B * P * Q; p.Ng = R * S * C;
   p.div_pq = make_fastdiv(P * Q); p.div_q = make_fastdiv(Q); p.div_c = make_fastdiv(C); p.div_s = make_fastdiv(S);
+  p.rowpat = 0;
+  for (int r = 0; r < R && r * S < 32; ++r) p.rowpat |= 1u << (r * S);
+  p.x_bytes = (unsigned)((size_t)B * H * W * C * 2);
+  p.dy_bytes = (unsigned)((size_t)B * P * Q * K * 2);
   MPR_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)K * p.Ng, st));
+
+  if (C % 64 == 0 && K % 64 == 0 && R * S <= 31 && p.Mpix >= g_wgrad_dma_min_pix) {
+    // LDS-DMA ring kernel: 64-pixel chunks, 2 workgroups per CU
+    const int WM = K <= 64 ? 1 : 2;
+    const int WN = p.Ng <= 64 ? 1 : ((C == 64 && p.Ng % 192 == 0) ? 3 : 2);
+    const int BM = 64 * WM, BN = 64 * WN;
+    p.ntm = ceil_div(K, BM); p.ntn = ceil_div(p.Ng, BN);
+    const int tiles = p.ntm * p.ntn;
+    const int total_chunks = ceil_div(p.Mpix, 64);
+    int nsplit = ceil_div(768, tiles);
+    if (nsplit > ceil_div(total_chunks, 4)) nsplit = ceil_div(total_chunks, 4);   // >= 4 chunks per split
+    if (nsplit < 1) nsplit = 1;
+    p.cps = ceil_div(total_chunks, nsplit);
+    nsplit = ceil_div(total_chunks, p.cps);
+    p.ngroups = p.ntm * nsplit;
+  dim3 grid(((p.ngroups + 7) / 8) * 8 * p.ntn);
+    void* tok = mpr_prof_begin(2, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
+#define MPR_WGD(WM_, WN_)                                                                             \
+  do {                                                                                                \
+    const size_t smem_ = (size_t)2 * 64 * (128 * WM_ + 128 * WN_);                             \
+    static bool attr_set = false;                                                                     \
+    if (!attr_set) {                                                                                  \
+      hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<WM_, WN_>,                               \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                     \
+      attr_set = true;                                                                                \
+    }                                                                                                 \
+    conv_wgrad_dma_kernel<WM_, WN_><<<grid, 64 * WM_ * WN_, smem_, st>>>(p);                          \
+  } while (0)
+    if (WM == 1 && WN == 1) MPR_WGD(1, 1);
+    else if (WM == 1 && WN == 2) MPR_WGD(1, 2);
+    else if (WM == 1 && WN == 3) MPR_WGD(1, 3);
+    else if (WM == 2 && WN == 1) MPR_WGD(2, 1);
+    else if (WM == 2 && WN == 2) MPR_WGD(2, 2);
+    else MPR_WGD(2, 3);
+#undef MPR_WGD
+    mpr_prof_end(tok, st);
+    MPR_LAUNCH_CHECK("conv_wgrad_dma_kernel");
+    const int total = K * C * R * S;
+    const int g2 = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
+    wgrad_unpack_kernel<<<g2, 256, 0, st>>>(workspace, dw_oihw, K, C, R, S, accumulate);
+    MPR_LAUNCH_CHECK("wgrad_unpack_kernel");
+    return MPR_OK;
+  }
 
   // tile shape: M = out channels (64 or 128 per WG), N = (tap, channel) columns in 64 / 128 / 192
   const int WM = K <= 64 ? 1 : 2;
@@ -216,7 +484,8 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   if (nsplit < 1) nsplit = 1;
   p.cps = ceil_div(total_chunks, nsplit);
   nsplit = ceil_div(total_chunks, p.cps);
-  dim3 grid(tiles * nsplit);
+  p.ngroups = p.ntm * nsplit;
+  dim3 grid(((p.ngroups + 7) / 8) * 8 * p.ntn);
 #define MPR_WG(WM_, WN_) conv_wgrad_kernel<WM_, WN_><<<grid, 64 * WM_ * WN_, 0, st>>>(p)
   void* tok = mpr_prof_begin(2, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
   if (WM == 1 && WN == 1) MPR_WG(1, 1);

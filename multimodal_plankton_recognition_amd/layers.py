@@ -147,7 +147,9 @@ class BasicBlockFn(torch.autograd.Function):
         dx2, dg2, db2, dz = ops.bn_bwd(dout, out, x2, g2, st2, MASK_Y, want_dz=True)
         dw2 = ops.conv_wgrad(a1, dx2, c2, w2.shape)
         da1 = ops.conv_dgrad(dx2, wd2, c2, a1.shape)
-        dx1, dg1, db1, _ = ops.bn_bwd(da1, a1, x1, g1, st1, MASK_Y)
+        # a1 = bf16(relu(x1*scale+shift)) has no residual: its ReLU mask is recomputed from x1 (bit-identical to
+        # a1 > 0) instead of re-reading a1 in both backward passes
+        dx1, dg1, db1, _ = ops.bn_bwd(da1, None, x1, g1, st1, MASK_RECOMPUTE)
         dw1 = ops.conv_wgrad(x, dx1, c1, w1.shape)
         if wd is not None:
             dxd, dgd, dbd, _ = ops.bn_bwd(dz, None, xd, gd, std, MASK_NONE)

@@ -55,9 +55,12 @@ CONV_CASES = [
 def igemm_path(request):
     """Run the conv tests through both implicit-GEMM kernels (register-staged / LDS-DMA ring)."""
     from multimodal_plankton_recognition_amd import _native
-    old = _native.query('mpr_conv_set_dma_min_rows', 0 if request.param == 'dma' else 1 << 30)
+    thr = 0 if request.param == 'dma' else 1 << 30
+    old = _native.query('mpr_conv_set_dma_min_rows', thr)
+    old_w = _native.query('mpr_conv_set_wgrad_dma_min_pixels', thr)
     yield request.param
     _native.query('mpr_conv_set_dma_min_rows', old)
+    _native.query('mpr_conv_set_wgrad_dma_min_pixels', old_w)
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
