@@ -99,6 +99,12 @@ int mpr_bn_relu_maxpool_fwd(const void* x, const float* scale /* NULL: plain max
                             int SH, int SW, int PH, int PW, void* stream);
 int mpr_maxpool_bwd(const void* dy, const void* idx, void* dx, int B, int H, int W, int C, int RH, int RW, int SH,
                     int SW, int PH, int PW, void* stream);
+/* stem backward, fused: max-pool gradient gathered on the fly inside both BatchNorm-backward passes
+ * (pass 0: partial sums -> mpr_bn_bwd_finalize -> pass 1: dx); the full-resolution gradient never exists */
+int mpr_pool_bn_bwd_rows(int B, int H, int W, int C);
+int mpr_pool_bn_bwd(int pass, const void* dy_pooled, const void* idx, const void* x, const float* scale,
+                    const float* shift, const float* mean, const float* invstd, const float* coef, float* partials,
+                    void* dx, int B, int H, int W, int C, int RH, int RW, int SH, int SW, int PH, int PW, void* stream);
 int mpr_global_avgpool_fwd(const void* x, float* y, int B, int L, int C, void* stream);
 int mpr_global_avgpool_bwd(const float* dy, void* dx, int B, int L, int C, void* stream);
 int mpr_global_maxpool_fwd(const void* x, float* y, int* idx, int B, int L, int C, void* stream);

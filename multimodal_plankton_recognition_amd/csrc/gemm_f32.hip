@@ -3,9 +3,12 @@
 // with its fp32 CPU path should be tight: the bias-free projection heads (src/model.py:31-32,40-41,80-82),
 // the classifier heads of ImageModel / ProfileModel (src/model.py:164,316) and the all-pairs similarity
 // matrix + its two gradient products in the coordination losses (src/coordination.py:38,89).
-//   C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b],   op = identity or transpose, row-major, any ld.
-// One workgroup = 4 waves = 64x64 of C; K in chunks of 16 staged k-major in LDS so that the MFMA
-// operands (lane -> row, lane>>5 -> k) are conflict-free ds_read_b32.
+//   C[b] = alpha * op(A[b]) * op(B[b]) (+ bias) + beta * C[b],   op = identity or transpose, row-major, any ld.
+// One workgroup = 4 waves = 64x64 of C, one 32x32 MFMA tile per wave.  K advances in chunks of 32 staged
+// k-major in double-buffered LDS (so the MFMA operands -- lane -> row, lane>>5 -> k -- are conflict-free
+// ds_read_b32); the global loads of chunk t+1 are issued before the 16 MFMAs of chunk t and written to the
+// other buffer after them: one barrier per chunk.  These problems are ~0.3 GFLOP each (latency-bound), so the
+// point is to keep loads in flight, not tile reuse.
 #include "common.h"
 
 struct GemmF32Params {
@@ -18,47 +21,68 @@ struct GemmF32Params {
   float alpha, beta;
 };
 
+#define GF_BK 32
+
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
-  __shared__ float As[16][64 + 4];
-  __shared__ float Bs[16][64 + 4];
+  __shared__ float As[2][GF_BK][64 + 4];
+  __shared__ float Bs[2][GF_BK][64 + 4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const float* A = p.A + (long long)blockIdx.z * p.sA;
   const float* B = p.B + (long long)blockIdx.z * p.sB;
   float* C = p.C + (long long)blockIdx.z * p.sC;
+
+  // per-thread staging coordinates: 8 elements of each operand per chunk, coalesced along the operand's
+  // contiguous axis
+  int am[8], ak[8], bn[8], bk[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 256 * i;
+    if (!p.transA) { ak[i] = idx & (GF_BK - 1); am[i] = idx / GF_BK; } else { am[i] = idx & 63; ak[i] = idx >> 6; }
+    if (!p.transB) { bn[i] = idx & 63; bk[i] = idx >> 6; } else { bk[i] = idx & (GF_BK - 1); bn[i] = idx / GF_BK; }
+  }
+  float ra[8], rb[8];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gm = m0 + am[i], gk = k0 + ak[i];
+      ra[i] = (gm < p.M && gk < p.K) ? (p.transA ? A[(long long)gk * p.lda + gm] : A[(long long)gm * p.lda + gk]) : 0.f;
+      const int gn = n0 + bn[i], gkb = k0 + bk[i];
+      rb[i] = (gn < p.N && gkb < p.K) ? (p.transB ? B[(long long)gn * p.ldb + gkb] : B[(long long)gkb * p.ldb + gn]) : 0.f;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      As[buf][ak[i]][am[i]] = ra[i];
+      Bs[buf][bk[i]][bn[i]] = rb[i];
+    }
+  };
+
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
-  for (int k0 = 0; k0 < p.K; k0 += 16) {
-    // stage 64x16 of op(A) and 16x64 of op(B); 4 elements per thread each, coalesced along the
-    // operand's contiguous axis
+  const int nk = (p.K + GF_BK - 1) / GF_BK;
+  if (nk > 0) {
+    load(0);
+    store(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nk) load((t + 1) * GF_BK);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i;
-      int m, k;
-      if (!p.transA) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
-      const int gm = m0 + m, gk = k0 + k;
-      float v = 0.f;
-      if (gm < p.M && gk < p.K) v = p.transA ? A[(long long)gk * p.lda + gm] : A[(long long)gm * p.lda + gk];
-      As[k][m] = v;
-      int n, kb;
-      if (!p.transB) { n = idx & 63; kb = idx >> 6; } else { kb = idx & 15; n = idx >> 4; }
-      const int gn = n0 + n, gkb = k0 + kb;
-      float w = 0.f;
-      if (gn < p.N && gkb < p.K) w = p.transB ? B[(long long)gn * p.ldb + gkb] : B[(long long)gkb * p.ldb + gn];
-      Bs[kb][n] = w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const float a = As[2 * s + (lane >> 5)][wm * 32 + (lane & 31)];
-      const float b = Bs[2 * s + (lane >> 5)][wn * 32 + (lane & 31)];
+    for (int s = 0; s < GF_BK / 2; ++s) {
+      const float a = As[cur][2 * s + (lane >> 5)][wm * 32 + (lane & 31)];
+      const float b = Bs[cur][2 * s + (lane >> 5)][wn * 32 + (lane & 31)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    if (t + 1 < nk) store(cur ^ 1);
     __syncthreads();
   }
+
   const int n = n0 + wn * 32 + (lane & 31);
   if (n < p.N) {
     const float bv = p.bias ? p.bias[n] : 0.f;

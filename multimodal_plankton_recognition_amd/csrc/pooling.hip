@@ -186,6 +186,109 @@ __global__ __launch_bounds__(256) void global_maxpool_bwd_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Stem backward with the max-pool gradient gathered on the fly: dz[b,ih,iw,c] = relu'(x*scale+shift) * (sum of the
+// pooled gradients of the windows that selected this position).  Used by both BatchNorm-backward passes, so the
+// full-resolution gradient (822 MB at batch 512) is never written and re-read.
+__device__ __forceinline__ void pool_grad_gather(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                 const PoolGeom& g, int b, int ih, int iw, int c8, int cg, float* acc) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  // strides are 1 or 2 (host-checked): no integer division.  Candidate windows per axis are listed first
+  // (<= 2 per axis for the 3/2/1 pooling of both stems), then only the valid (row, column) pairs are visited.
+  // (window <= 2*stride per axis, host-checked => at most two candidates per axis, kept in named registers)
+  int q0 = -1, q1 = -1, kw0 = 0, kw1 = 0;
+  for (int kw = 0; kw < g.RW; ++kw) {
+    int q = iw + g.PW - kw;
+    if (q < 0) continue;
+    if (g.SW == 2) { if (q & 1) continue; q >>= 1; }
+    if (q >= g.Q) continue;
+    if (q0 < 0) { q0 = q; kw0 = kw; } else { q1 = q; kw1 = kw; }
+  }
+  for (int kh = 0; kh < g.RH; ++kh) {
+    int p = ih + g.PH - kh;
+    if (p < 0) continue;
+    if (g.SH == 2) { if (p & 1) continue; p >>= 1; }
+    if (p >= g.P) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int q = a ? q1 : q0, kw = a ? kw1 : kw0;
+      if (q < 0) continue;
+      const unsigned o = ((unsigned)(b * g.P + p) * g.Q + q) * cg + c8;
+      const uint2 pk = reinterpret_cast<const uint2*>(idx)[o];
+      float d[8];
+      unpack8(reinterpret_cast<const uint4*>(dy)[o], d);
+      const unsigned tap = kh * g.RW + kw;
+      const unsigned tap4 = tap * 0x01010101u;
+      const unsigned m0 = pk.x ^ tap4, m1 = pk.y ^ tap4;     // a zero byte marks a lane whose arg-max is this tap
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (((m0 >> (8 * e)) & 0xff) == 0) acc[e] += d[e];
+        if (((m1 >> (8 * e)) & 0xff) == 0) acc[4 + e] += d[4 + e];
+      }
+    }
+  }
+}
+
+// PASS 0: partial sums (sum dz, sum dz*xhat) -> partials [grid][2][C];  PASS 1: dx = k1*dz + k2*x + k3
+template <int PASS>
+__global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const bf16_t* __restrict__ dy,
+                                                          const unsigned char* __restrict__ idx,
+                                                          const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                          float* __restrict__ partials, bf16_t* __restrict__ dx, PoolGeom g,
+                                                          FastDiv div_cg, FastDiv div_hw, FastDiv div_w) {
+  const int cg = g.C >> 3;
+  const int nthr = blockDim.x;                    // a multiple of cg: the channel group is thread-invariant
+  const int c8 = threadIdx.x % cg;
+  __shared__ float red[PASS == 0 ? 256 : 1][17];
+  float sc[8], sh[8], p1[8], p2[8], p3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = scale[c8 * 8 + e];
+    sh[e] = shift[c8 * 8 + e];
+    if (PASS == 0) { p1[e] = mean[c8 * 8 + e]; p2[e] = invstd[c8 * 8 + e]; p3[e] = 0.f; }
+    else { p1[e] = coef[c8 * 8 + e]; p2[e] = coef[g.C + c8 * 8 + e]; p3[e] = coef[2 * g.C + c8 * 8 + e]; }
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  const unsigned total = (unsigned)g.B * g.H * g.W * cg;
+  for (unsigned v = blockIdx.x * nthr + threadIdx.x; v < total; v += gridDim.x * nthr) {
+    const unsigned pix = fdiv(v, div_cg);                    // v = pix*cg + c8
+    const unsigned b = fdiv(pix, div_hw);
+    const unsigned rem = pix - b * (unsigned)(g.H * g.W);
+    const int ih = fdiv(rem, div_w);
+    const int iw = rem - ih * g.W;
+    float xf[8], dz[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[v], xf);
+    pool_grad_gather(dy, idx, g, b, ih, iw, c8, cg, dz);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dz[e] = round_bf16(fmaf(xf[e], sc[e], sh[e])) > 0.f ? dz[e] : 0.f;
+    if (PASS == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += dz[e]; s2[e] += dz[e] * (xf[e] - p1[e]) * p2[e]; }
+    } else {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf(p1[e], dz[e], fmaf(p2[e], xf[e], p3[e]));
+      reinterpret_cast<uint4*>(dx)[v] = pack8(o);
+    }
+  }
+  if (PASS == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cg * 16; i += nthr) {
+      const int gg = i >> 4, e = i & 15;
+      float a = 0.f;
+      for (int t = gg; t < nthr; t += cg) a += red[t][e];
+      partials[((size_t)blockIdx.x * 2 + (e >> 3)) * g.C + gg * 8 + (e & 7)] = a;
+    }
+  }
+}
+
 static inline int ew_grid(long long n, int block) {
   long long g = (n + block - 1) / block;
   return (int)(g < 4096 ? (g < 1 ? 1 : g) : 4096);
@@ -217,6 +320,40 @@ int mpr_maxpool_bwd(const void* dy, const void* idx, void* dx, int B, int H, int
   maxpool_bwd_kernel<<<ew_grid(total, 256), 256, 0, (hipStream_t)stream>>>((const bf16_t*)dy,
                                                                            (const unsigned char*)idx, (bf16_t*)dx, g);
   MPR_LAUNCH_CHECK("maxpool_bwd_kernel");
+  return MPR_OK;
+}
+
+static inline int pool_bn_block(int C) { return (256 / (C / 8)) * (C / 8); }
+
+int mpr_pool_bn_bwd_rows(int B, int H, int W, int C) {
+  const long long nvec = (long long)B * H * W * (C / 8);
+  const int block = pool_bn_block(C);
+  long long g = (nvec + block - 1) / block;
+  return (int)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
+}
+
+// Fused (max-pool backward -> ReLU mask -> BatchNorm backward) for the stem: pass 0 writes partial sums
+// [mpr_pool_bn_bwd_rows][2][C]; pass 1 (after mpr_bn_bwd_finalize gave coef) writes dx [B,H,W,C].
+int mpr_pool_bn_bwd(int pass, const void* dy_pooled, const void* idx, const void* x, const float* scale,
+                    const float* shift, const float* mean, const float* invstd, const float* coef, float* partials,
+                    void* dx, int B, int H, int W, int C, int RH, int RW, int SH, int SW, int PH, int PW, void* stream) {
+  MPR_REQUIRE(dy_pooled && idx && x && scale && shift, "mpr_pool_bn_bwd: null pointer");
+  MPR_REQUIRE(C % 8 == 0 && C / 8 <= 256, "mpr_pool_bn_bwd: C must be a multiple of 8, <= 2048 (got %d)", C);
+  MPR_REQUIRE((long long)B * H * W * C < (1ll << 31), "mpr_pool_bn_bwd: tensor exceeds 2^31 elements");
+  MPR_REQUIRE(pass == 0 ? (mean && invstd && partials) : (coef && dx), "mpr_pool_bn_bwd: missing pass operands");
+  PoolGeom g = {B, H, W, C, (H + 2 * PH - RH) / SH + 1, (W + 2 * PW - RW) / SW + 1, RH, RW, SH, SW, PH, PW};
+  const int block = pool_bn_block(C), grid = mpr_pool_bn_bwd_rows(B, H, W, C);
+  hipStream_t st = (hipStream_t)stream;
+  MPR_REQUIRE((SH == 1 || SH == 2) && (SW == 1 || SW == 2), "mpr_pool_bn_bwd: strides must be 1 or 2");
+  MPR_REQUIRE(RW <= 2 * SW, "mpr_pool_bn_bwd: window width %d > 2 * stride %d is not supported", RW, SW);
+  const FastDiv dcg = make_fastdiv(C / 8), dhw = make_fastdiv(H * W), dw = make_fastdiv(W);
+  if (pass == 0)
+    pool_bn_bwd_kernel<0><<<grid, block, 0, st>>>((const bf16_t*)dy_pooled, (const unsigned char*)idx, (const bf16_t*)x,
+                                                  scale, shift, mean, invstd, nullptr, partials, nullptr, g, dcg, dhw, dw);
+  else
+    pool_bn_bwd_kernel<1><<<grid, block, 0, st>>>((const bf16_t*)dy_pooled, (const unsigned char*)idx, (const bf16_t*)x,
+                                                  scale, shift, nullptr, nullptr, coef, nullptr, (bf16_t*)dx, g, dcg, dhw, dw);
+  MPR_LAUNCH_CHECK("pool_bn_bwd_kernel");
   return MPR_OK;
 }
 

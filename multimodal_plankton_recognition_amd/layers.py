@@ -95,8 +95,7 @@ class StemFn(torch.autograd.Function):
         if not ctx.train:
             raise RuntimeError('backward through an eval-mode BatchNorm stem is not implemented')
         x, y, idx, conv_w, bn_w = ctx.saved_tensors
-        da = ops.maxpool_bwd(dpooled.contiguous(), idx, y.shape)
-        dx, dgamma, dbeta, _ = ops.bn_bwd(da, None, y, bn_w, ctx.st, MASK_RECOMPUTE)
+        dx, dgamma, dbeta = ops.pool_bn_bwd(dpooled.contiguous(), idx, y, bn_w, ctx.st)
         if ctx.s2d:
             dw = ops.stem_s2d_wgrad(x, dx, ctx.g, conv_w.shape)
         else:

@@ -4,6 +4,7 @@ Same constructor arguments, attribute names, ``state_dict`` keys and step method
 reference's LightningModules (``lightning`` itself is absent here; ``trainer.Trainer`` drives the
 same hooks).  All arithmetic below the module boundary runs on the gfx950 kernels.
 """
+import os
 from typing import Any, Callable, Dict
 
 import torch
@@ -81,6 +82,10 @@ class MultiModel(_StepModule):
         self.optim_args = optim_args
         self.train_loss = []
         self.valid_loss = []
+        # overlap the profile branch with the image branch (see encode); MPR_TWO_STREAMS=0 serialises them
+        # (per-kernel profiles are only attributable without the overlap)
+        self.two_streams = os.environ.get('MPR_TWO_STREAMS', '1') != '0'
+        self._side_stream = None
 
     def safe_forward(self, model: Callable, **kwargs):
         return model(**kwargs) if not any(v is None for v in kwargs.values()) else None
@@ -90,6 +95,25 @@ class MultiModel(_StepModule):
 
     def encode(self, image, profile, **kwargs) -> Dict[str, Tensor]:
         # every other batch key is forwarded to BOTH encoders (src/model.py:72-85)
+        both = image is not None and profile is not None and getattr(image, 'is_cuda', False)
+        if both and self.two_streams:
+            # the two branches are independent until the loss: the (small, latency-bound) profile kernels run on
+            # a second HIP stream underneath the image branch; autograd replays each branch's backward on the
+            # stream its forward ran on, so the overlap carries over to the backward pass
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                profile_emb = self.safe_forward(self.profile_encoder, profile=profile, **kwargs)
+                profile_emb = self.safe_forward(self.profile_projection, input=profile_emb)
+            image_emb = self.safe_forward(self.image_encoder, image=image, **kwargs)
+            image_emb = self.safe_forward(self.image_projection, input=image_emb)
+            main.wait_stream(side)
+            if profile_emb is not None:
+                profile_emb.record_stream(main)
+            return {'image_emb': image_emb, 'profile_emb': profile_emb}
         image_emb = self.safe_forward(self.image_encoder, image=image, **kwargs)
         profile_emb = self.safe_forward(self.profile_encoder, profile=profile, **kwargs)
         image_emb = self.safe_forward(self.image_projection, input=image_emb)

@@ -233,6 +233,25 @@ def maxpool_bwd(dy, idx, x_shape, k=3, s=2, p=1):
     return dx
 
 
+def pool_bn_bwd(dpooled, idx, x, gamma, st, k=3, s=2, p=1):
+    """Stem backward, fused: maxpool-backward gather + ReLU mask + BatchNorm backward.  -> dx, dgamma, dbeta."""
+    B, H, W, C, RH, RW, SH, SW, PH, PW = _pool_geom(x, k, s, p)
+    dev = x.device
+    rows = x.numel() // C
+    parts = torch.empty(N.query('mpr_pool_bn_bwd_rows', B, H, W, C), 2, C, dtype=F32, device=dev)
+    geo = (B, H, W, C, RH, RW, SH, SW, PH, PW)
+    N.call('mpr_pool_bn_bwd', 0, dpooled, idx, x, st.scale, st.shift, st.mean, st.invstd, None, parts, None, *geo)
+    parts = _prereduce(parts)
+    dgamma = torch.empty(C, dtype=F32, device=dev)
+    dbeta = torch.empty(C, dtype=F32, device=dev)
+    coef = torch.empty(3, C, dtype=F32, device=dev)
+    N.call('mpr_bn_bwd_finalize', parts, parts.shape[0], rows, gamma.detach(), st.mean, st.invstd, dgamma, dbeta, 0,
+           coef, C)
+    dx = torch.empty_like(x)
+    N.call('mpr_pool_bn_bwd', 1, dpooled, idx, x, st.scale, st.shift, None, None, coef, None, dx, *geo)
+    return dx, dgamma, dbeta
+
+
 def global_pool_fwd(x, mode):
     B, C = x.shape[0], x.shape[-1]
     L = x.numel() // (B * C)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_size_queries_match_documented_tiling():
     assert _native.query('mpr_conv_fwd_stat_rows', 512, 56, 56, 64, 64, 3, 3) == 512 * 56 * 56 // 256
-    assert _native.query('mpr_conv_fwd_stat_rows', 512, 28, 28, 128, 128, 3, 3) == 512 * 28 * 28 // 256
+    assert _native.query('mpr_conv_fwd_stat_rows', 512, 28, 28, 128, 128, 3, 3) == 512 * 28 * 28 // 128
     assert _native.query('mpr_conv_fwd_stat_rows', 4, 28, 28, 128, 128, 3, 3) == 4 * 28 * 28 // 128 + 1
     assert _native.query('mpr_loss_workspace_floats') >= 1024
 
