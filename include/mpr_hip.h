@@ -117,6 +117,34 @@ int mpr_gemm_f32(const float* A, const float* B, float* C, const float* bias /* 
                  int lda, int ldb, int ldc, int transA, int transB, float alpha, float beta, int batch,
                  long long strideA, long long strideB, long long strideC, void* stream);
 
+int mpr_gemm_f32_b2(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                    int transB, float alpha, float beta, int outer, int inner, long long sAo, long long sAi,
+                    long long sBo, long long sBi, long long sCo, long long sCi, void* stream);
+
+/* ---- transformer encoder pieces, fp32 (ProfileTransformer: nn.TransformerEncoderLayer at
+ *      src/profile_encoder.py:22-30,57-68; timm VisionTransformer blocks behind src/image_encoder.py:16,24).
+ *      The GEMMs run on mpr_gemm_f32 / mpr_gemm_f32_b2. */
+int mpr_add_layernorm_fwd(const float* x, const float* residual /* may be NULL */, const float* gamma,
+                          const float* beta, float eps, float* y, float* sum_out /* x + residual, may be NULL */,
+                          float* mean, float* rstd, int rows, int D, void* stream);
+int mpr_layernorm_bwd_workspace_floats(int rows, int D);
+int mpr_layernorm_bwd(const float* dy, const float* s, const float* gamma, const float* mean, const float* rstd,
+                      const float* dskip /* may be NULL */, float* ds, float* dgamma, float* dbeta, float* workspace,
+                      int accumulate, int rows, int D, void* stream);
+int mpr_masked_softmax_fwd(float* S /* [batch*heads*Tq][T], in place */, const void* key_padding_mask /* [batch][T] bytes or NULL */,
+                           float scale, int batch, int heads, int Tq, int T, void* stream);
+int mpr_softmax_bwd(float* dP /* in place -> dS */, const float* P, float scale, int rows, int T, void* stream);
+/* act: 0 none, 1 exact GELU, 2 ReLU; optional inverted dropout (mask: 1 byte / element) */
+int mpr_bias_act_fwd(const float* x, const float* bias /* [D] or NULL */, int act, float p_drop, unsigned seed, float* y,
+                     void* mask, long long n, int D, void* stream);
+int mpr_bias_act_bwd(const float* dy, const float* x, const float* bias, int act, float p_drop, const void* mask,
+                     float* dx, long long n, int D, void* stream);
+int mpr_embedding_add_fwd(const float* x, const float* table, const long long* index, float* y, int rows, int D,
+                          void* stream);
+int mpr_embedding_bwd(const float* dy, const long long* index, float* dtable, int table_rows, int rows, int D,
+                      long long padding_idx, void* stream);
+int mpr_add_f32(const float* a, const float* b, float* y, long long n, void* stream);
+
 /* ---- coordination losses (src/coordination.py:17-112) ----------------------------------------- */
 int mpr_loss_workspace_floats(void);
 int mpr_l2norm_fwd(const float* x, float* u, float* inv_norm, int rows, int D, void* stream);

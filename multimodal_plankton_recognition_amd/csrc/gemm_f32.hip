@@ -17,7 +17,9 @@ struct GemmF32Params {
   float* C;
   const float* bias;   // optional [N], added to every row
   int M, N, K, lda, ldb, ldc, transA, transB;
-  long long sA, sB, sC;
+  long long sA, sB, sC;      // outer batch strides
+  int inner;                 // two-level batch: z = outer_index * inner + inner_index
+  long long iA, iB, iC;      // inner batch strides
   float alpha, beta;
 };
 
@@ -29,9 +31,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const float* A = p.A + (long long)blockIdx.z * p.sA;
-  const float* B = p.B + (long long)blockIdx.z * p.sB;
-  float* C = p.C + (long long)blockIdx.z * p.sC;
+  const int zo = blockIdx.z / p.inner, zi = blockIdx.z - zo * p.inner;
+  const float* A = p.A + (long long)zo * p.sA + (long long)zi * p.iA;
+  const float* B = p.B + (long long)zo * p.sB + (long long)zi * p.iB;
+  float* C = p.C + (long long)zo * p.sC + (long long)zi * p.iC;
 
   // per-thread staging coordinates: 8 elements of each operand per chunk, coalesced along the operand's
   // contiguous axis
@@ -106,8 +109,23 @@ int mpr_gemm_f32(const float* A, const float* B, float* C, const float* bias, in
                  long long strideB, long long strideC, void* stream) {
   MPR_REQUIRE(A && B && C, "mpr_gemm_f32: null pointer");
   MPR_REQUIRE(M > 0 && N > 0 && K >= 0 && batch > 0, "mpr_gemm_f32: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
-  GemmF32Params p = {A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, strideA, strideB, strideC, alpha, beta};
+  GemmF32Params p = {A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, strideA, strideB, strideC, 1, 0, 0, 0, alpha, beta};
   dim3 grid(ceil_div(N, 64), ceil_div(M, 64), batch);
+  gemm_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
+  MPR_LAUNCH_CHECK("gemm_f32_kernel");
+  return MPR_OK;
+}
+
+// Two-level batch (e.g. batch x heads with operands that are strided slices of one packed tensor):
+// problem z = o * inner + i uses A + o*sAo + i*sAi, etc.
+int mpr_gemm_f32_b2(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                    int transB, float alpha, float beta, int outer, int inner, long long sAo, long long sAi, long long sBo,
+                    long long sBi, long long sCo, long long sCi, void* stream) {
+  MPR_REQUIRE(A && B && C, "mpr_gemm_f32_b2: null pointer");
+  MPR_REQUIRE(M > 0 && N > 0 && K >= 0 && outer > 0 && inner > 0 && (long long)outer * inner <= 65535,
+              "mpr_gemm_f32_b2: bad sizes M=%d N=%d K=%d batch=%dx%d", M, N, K, outer, inner);
+  GemmF32Params p = {A, B, C, nullptr, M, N, K, lda, ldb, ldc, transA, transB, sAo, sBo, sCo, inner, sAi, sBi, sCi, alpha, beta};
+  dim3 grid(ceil_div(N, 64), ceil_div(M, 64), outer * inner);
   gemm_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
   MPR_LAUNCH_CHECK("gemm_f32_kernel");
   return MPR_OK;

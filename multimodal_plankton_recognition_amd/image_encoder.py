@@ -59,12 +59,92 @@ class ResNetBackbone(nn.Module):
         return out
 
 
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _ViTBlock(nn.Module):
+    """Parameter container with timm's Block key names (norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2)."""
+
+    def __init__(self, dim, mlp_ratio=4):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attn(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, dim * mlp_ratio)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, in_chans, dim, patch):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, dim, patch, patch)
+
+
+class ViTBackbone(nn.Module):
+    """timm VisionTransformer (pre-norm blocks, LN eps 1e-6, qkv bias, exact GELU, CLS pooling, learned position
+    embedding); timm ``state_dict`` key names.  Arithmetic: ``transformer.py`` (fp32 kernels)."""
+
+    def __init__(self, embed_dim=768, depth=12, num_heads=12, patch=16, img_size=224, in_chans: int = 1):
+        super().__init__()
+        self.patch, self.num_heads, self.num_features = patch, num_heads, embed_dim
+        n_tok = (img_size // patch) ** 2 + 1
+        self.patch_embed = _PatchEmbed(in_chans, embed_dim, patch)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, n_tok, embed_dim) * .02)
+        self.blocks = nn.Sequential(*[_ViTBlock(embed_dim) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():            # timm: trunc_normal(.02) weights, zero biases, LN (1, 0)
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                nn.init.zeros_(m.bias)
+
+    def forward_tokens(self, image: Tensor) -> Tensor:
+        from . import transformer as TF
+        from .layers import linear
+        B, C, H, W = image.shape
+        P = self.patch
+        d = self.num_features
+        gh, gw = H // P, W // P
+        # conv-as-GEMM patch embedding: [B, gh*gw, C*P*P] x [d, C*P*P]^T
+        patches = image.float().reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * P * P)
+        x = linear(patches.contiguous(), self.patch_embed.proj.weight.view(d, -1), self.patch_embed.proj.bias)
+        x = torch.cat((self.cls_token.expand(B, 1, d), x.view(B, gh * gw, d)), 1).contiguous()
+        T = x.shape[1]
+        index = torch.arange(T, device=x.device).repeat(B)
+        x = TF.EmbeddingAddFn.apply(x.view(B * T, d), self.pos_embed.view(-1, d), index, None).view(B, T, d)
+        for blk in self.blocks:
+            x = TF.pre_norm_block(blk, x, self.num_heads, 0.0, self.training)
+        x = TF.add_layer_norm(x.reshape(B * T, d), None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x.view(B, T, d)
+
+    def forward_pooled(self, image: Tensor) -> Tensor:
+        return self.forward_tokens(image)[:, 0].contiguous()          # global_pool='token'
+
+
+_VITS = {'vit_tiny_patch16_224': (192, 12, 3, 16), 'vit_small_patch16_224': (384, 12, 6, 16),
+         'vit_base_patch16_224': (768, 12, 12, 16), 'vit_small_patch32_224': (384, 12, 6, 32)}
+
+
 def create_backbone(name: str, in_chans: int = 1):
     if name in _RESNETS and _RESNETS[name] is not None:
         return ResNetBackbone(_RESNETS[name], in_chans)
+    if name in _VITS:
+        dim, depth, heads, patch = _VITS[name]
+        return ViTBackbone(dim, depth, heads, patch, 224, in_chans)
     raise NotImplementedError(
-        f"image backbone '{name}': only BasicBlock ResNets ({', '.join(k for k, v in _RESNETS.items() if v)}) "
-        f"have native gfx950 kernels so far")
+        f"image backbone '{name}': BasicBlock ResNets ({', '.join(k for k, v in _RESNETS.items() if v)}) and ViTs "
+        f"({', '.join(_VITS)}) have native gfx950 kernels so far")
 
 
 class ImageEncoder(nn.Module):
@@ -81,7 +161,10 @@ class ImageEncoder(nn.Module):
         self.p_drop = float(dropout)
 
     def forward(self, image: Tensor, **kwargs) -> Tensor:
-        fmap = self.backbone.forward_features(image)
         meta = kwargs['image_shape'].contiguous() if self.metadata else None     # (orig H, W) / tensor H  (:26-27)
         p = self.p_drop if self.training else 0.0
+        if isinstance(self.backbone, ViTBackbone):
+            from .layers import TailFn
+            return TailFn.apply(self.backbone.forward_pooled(image), meta, image.shape[2], p)
+        fmap = self.backbone.forward_features(image)
         return PoolTailFn.apply(fmap, meta, 'avg', image.shape[2], p)

@@ -72,9 +72,10 @@ class ProfileCNN(nn.Module):
 
 
 class ProfileTransformer(nn.Module):
-    """Placeholder keeping the reference's constructor / tokenize contract
-    (src/profile_encoder.py:9-68).  The native attention / LayerNorm / GELU-MLP kernels are not
-    built yet, so ``forward`` raises instead of silently running torch ops."""
+    """Transformer profile encoder, reference src/profile_encoder.py:9-68.  The torch modules below are
+    parameter containers only (same ``state_dict`` keys and default initialisation as the reference);
+    ``forward`` runs LayerNorm / attention / GELU-MLP / embedding on the gfx950 kernels in exact fp32
+    (``transformer.py``)."""
 
     def __init__(self, dim_in: int, dim_hidden: int, target_size: int, num_head: int, num_layers: int = 6,
                  dim_feedforward: int = 2024, dropout: float = 0.1, activation: str = 'gelu',
@@ -104,8 +105,18 @@ class ProfileTransformer(nn.Module):
         return {'profile': prof, 'time': time, 'padding_mask': time == self.padding_idx}
 
     def forward(self, profile: Tensor, time: Tensor, padding_mask: Tensor, **kwargs) -> Tensor:
-        raise NotImplementedError('ProfileTransformer: native gfx950 attention path not built yet '
-                                  '(no torch fallback is provided on purpose)')
+        # src/profile_encoder.py:57-68: expand + position(time) -> post-norm encoder (key-padding mask) -> CLS
+        from . import transformer as TF
+        from .layers import TailFn, linear
+        B, T, _ = profile.shape
+        d = self.expand.weight.shape[0]
+        x = linear(profile.reshape(B * T, -1).float().contiguous(), self.expand.weight)
+        x = TF.EmbeddingAddFn.apply(x, self.position.weight, time, self.padding_idx).view(B, T, d)
+        for layer in self.encoder.layers:
+            x = TF.post_norm_layer(layer, x, padding_mask, self.p_drop, self.training)
+        cls = x[:, 0].contiguous()
+        meta = kwargs['profile_len'].contiguous() if self.metadata else None
+        return TailFn.apply(cls, meta, profile.shape[1], self.p_drop if self.training else 0.0)
 
 
 class ProfileLSTM(nn.Module):
