@@ -6,7 +6,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with hipEvent pairs around every launch of
-the dominant kernel (conv_igemm_kernel, forward + dgrad instantiations) inside the timed region;
+the dominant kernel (conv_igemm_dma_kernel, forward + dgrad instantiations) inside the timed region;
 `cpu_baseline` times the CPU oracle (plain-torch fp32 restatement of the same step) on a bounded sample.
 """
 import argparse
@@ -164,13 +164,15 @@ def main():
                        'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'loss': round(loss_val, 5)},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (fwd + dgrad instantiations)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma_kernel (forward + data-gradient instantiations, image branch)',
                          'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
                          'launches': ig_n, 'avg_launch_us': round(ig_ms * 1e3 / max(ig_n, 1), 2),
                          'share_of_step_time': round(ig_ms / args.steps / ms_per_step, 3),
-                         'wgrad_kernel': {'achieved': round(w_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
-                                          'launches': n_w, 'share_of_step_time': round(ms_w / args.steps / ms_per_step, 3)}},
+                         'wgrad_kernel': {'name': 'conv_wgrad_dma_kernel',
+                                          'achieved': round(w_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
+                                          'launches': n_w, 'share_of_step_time': round(ms_w / args.steps / ms_per_step, 3)},
+                         'note': 'event-timed on the launch stream while the profile branch runs on a second stream'},
         }
         if world == 1 and not args.no_cpu_baseline:
             # host share of a 1-GPU box is 16 cores (the node reports all of them): never oversubscribe

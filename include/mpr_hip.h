@@ -28,7 +28,8 @@ const char* mpr_target_arch(void);                 /* "gfx950" */
 const char* mpr_last_error(void);
 void mpr_set_error(const char* fmt, ...);
 int mpr_device_check(char* name, int name_len);    /* 0 iff device 0 is gfx950; name: HOST buffer */
-/* opt-in hipEvent profiler around the conv kernels (kinds: 0 igemm fwd, 1 igemm dgrad, 2 wgrad);
+/* opt-in hipEvent profiler around the conv kernels (kinds: 0/1 LDS-DMA igemm fwd/dgrad, 2 LDS-DMA wgrad,
+ * 3/4 register-staged igemm fwd/dgrad, 5 register-staged wgrad);
  * collect sums elapsed ms / algorithmic FLOPs / launches into HOST variables (kind -1: all). */
 int mpr_prof_enable(int on);
 int mpr_prof_reset(void);
@@ -46,6 +47,9 @@ int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S);
 int mpr_conv_set_dma_min_rows(int rows);
 /* tile / ring-depth variant of the LDS-DMA kernel (tuning knob, see conv_igemm.hip; default 0, 0) */
 int mpr_conv_set_variant(int narrow, int wide);
+/* stride-2 data gradient: regroup rows into the 4 (h mod 2, w mod 2) classes so a tile walks only the taps that
+ * reach it (default 1 = on; 0 = issue every tap with zero-filled holes); returns the previous setting */
+int mpr_conv_set_dgrad_parity(int on);
 /* output pixels (B*P*Q) from which the LDS-DMA weight-gradient kernel is used (default 16384) */
 int mpr_conv_set_wgrad_dma_min_pixels(int pixels);
 int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may be NULL */, int B, int H, int W,

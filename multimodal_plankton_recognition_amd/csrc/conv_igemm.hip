@@ -31,6 +31,7 @@ struct ConvGemmParams {
   int R, S, sh, sw, ph, pw;
   FastDiv div_pq, div_q;   // row m -> (b, p, q)
   int Pm, Qm;
+  int par_rows, par_valid;   // stride-2 dgrad parity classes (LDS-DMA kernel): padded / real rows per class, 0 = off
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {   // byte offset in a [rows][128 B] tile
@@ -273,17 +274,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   //   dgrad: pix = rbase + ((rh - r)/sh)*sW + (rw - s)/sw  (when valid) -> ch = -2*sC*sW/sh,  cw = -2*sC/sw
   const int tstep_h = DGRAD ? -(2 * p.sC * p.sW) / p.sh : 2 * p.sC * p.sW;
   const int tstep_w = DGRAD ? -(2 * p.sC) / p.sw : 2 * p.sC;
+  // Stride-2 data gradient, parity classes (p.par_rows > 0): only taps with r == (h + ph) mod 2 and
+  // s == (w + pw) mod 2 reach a gradient pixel, so the rows are regrouped by (h mod 2, w mod 2) -- a tile
+  // then belongs to ONE class and simply skips the other taps (1/4 of the chunks on average instead of
+  // issuing all of them with 3/4 of the rows zero-filled).  Row m -> class m / par_rows, and
+  // (b, h/2, w/2) = decode(m mod par_rows) with Pm = H/2, Qm = W/2.
+  const bool PAR = DGRAD && p.par_rows > 0;
+  const int cls = PAR ? m0 / p.par_rows : 0;
+  const int par_h = cls >> 1, par_w = cls & 1;
+  const int mbase = cls * p.par_rows;
   uint32_t voff[A_IT], vmask[A_IT];
 #pragma unroll
   for (int j = 0; j < A_IT; ++j) {
-    const int m = m0 + 8 * (wid * A_IT + j) + lrow;
+    const int m = m0 + 8 * (wid * A_IT + j) + lrow - mbase;
     voff[j] = 0;
     vmask[j] = 0;
-    if (m < p.M) {
+    if (m < (PAR ? p.par_valid : p.M)) {
       const uint32_t b = fdiv(m, p.div_pq);
       const uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
-      const uint32_t pp = fdiv(rem, p.div_q);
-      const uint32_t qq = rem - pp * p.Qm;
+      uint32_t pp = fdiv(rem, p.div_q);
+      uint32_t qq = rem - pp * p.Qm;
+      if (PAR) { pp = 2 * pp + par_h; qq = 2 * qq + par_w; }
       int rh, rw;
       if (!DGRAD) { rh = (int)pp * p.sh - p.ph; rw = (int)qq * p.sw - p.pw; }
       else        { rh = (int)pp + p.ph;        rw = (int)qq + p.pw; }
@@ -340,12 +351,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
 
   const int ncb = p.sC >> 6;     // 64-channel blocks per tap
   const int ntaps = p.R * p.S;
-  int tr = 0, ts = 0, cb = 0, tap = 0;    // wave-uniform tap state of the NEXT chunk to issue
+  // parity classes walk only the taps r = tr0, tr0+2, ... / s = ts0, ts0+2, ... of their class
+  const int tr0 = PAR ? ((par_h + p.ph) & 1) : 0, ts0 = PAR ? ((par_w + p.pw) & 1) : 0;
+  const int tstep = PAR ? 2 : 1;
+  const int nk = PAR ? ((p.R - tr0 + 1) >> 1) * ((p.S - ts0 + 1) >> 1) * ncb : p.nk;
+  int tr = tr0, ts = ts0, cb = 0, tap = tr0 * p.S + ts0;    // wave-uniform tap state of the NEXT chunk to issue
   auto issue_chunk = [&](int kc, int buf) {
     unsigned char* sa = smem + buf * STAGE;
     unsigned char* sb = sa + A_BYTES;
     const uint32_t toff = (uint32_t)(tr * tstep_h + ts * tstep_w + cb * 128);
     const uint32_t bit = tap < ntaps ? (1u << tap) : 0u;      // K padding chunks: every lane reads zeros
+    if (PAR) kc = tap * ncb + cb;                             // weight chunk of this (tap, channel block)
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
       const uint32_t v = (vmask[j] & bit) ? voff[j] + toff : 0xFFFFFFF0u;
@@ -356,7 +372,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     for (int j = 0; j < B_IT; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(sb + (wid * B_IT + j) * 1024),
                                                16, boff[j], kc * 128, 0, 0);
-    if (++cb == ncb) { cb = 0; ++tap; if (++ts == p.S) { ts = 0; ++tr; } }
+    if (++cb == ncb) {
+      cb = 0;
+      ts += tstep;
+      if (ts >= p.S) { ts = ts0; tr += tstep; }
+      tap = tr * p.S + ts;
+    }
   };
 
   f32x16 acc[2][2];
@@ -368,7 +389,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   int issued = 0;
-  for (; issued < STAGES - 1 && issued < p.nk; ++issued) issue_chunk(issued, issued % STAGES);
+  for (; issued < STAGES - 1 && issued < nk; ++issued) issue_chunk(issued, issued % STAGES);
 
   const int frow = lane & 31, fh = lane >> 5;
   // fragment read offsets inside a stage: row*128 + (((2*ks + fh) ^ key) << 4), key = (row >> 1) & 7 = (frow >> 1) & 7
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
       a_rd[t][ks] = swz_off(wm * 64 + t * 32 + frow, ks * 2 + fh);
       b_rd[t][ks] = A_BYTES + swz_off(wn * 64 + t * 32 + frow, ks * 2 + fh);
     }
-  for (int kc = 0; kc < p.nk; ++kc) {
+  for (int kc = 0; kc < nk; ++kc) {
     // retire chunk kc: everything but the (issued - kc - 1) younger chunks of THIS wave must have landed
     const int younger = issued - kc - 1;
     if (STAGES >= 3 && younger >= STAGES - 2) wait_vmcnt<(STAGES - 2) * IPC>();
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (issued < p.nk) { issue_chunk(issued, issued % STAGES); ++issued; }
+    if (issued < nk) { issue_chunk(issued, issued % STAGES); ++issued; }
     const unsigned char* a = smem + (kc % STAGES) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -432,8 +453,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll 4
   for (int r = rr; r < BM; r += RPP) {
-    const int m = m0 + r;
-    if (m < p.M && col_ok) {
+    int m = m0 + r - mbase;
+    bool row_ok = m < (PAR ? p.par_valid : p.M);
+    if (PAR && row_ok) {     // class-local row -> pixel (b, 2*h2 + par_h, 2*w2 + par_w) of the [B, 2*Pm, 2*Qm] gradient
+      const uint32_t b = fdiv(m, p.div_pq);
+      const uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
+      const uint32_t h2 = fdiv(rem, p.div_q);
+      const uint32_t w2 = rem - h2 * p.Qm;
+      m = ((b * 2 * p.Pm + 2 * h2 + par_h) * 2 * p.Qm) + 2 * w2 + par_w;
+    }
+    if (row_ok && col_ok) {
       const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
       const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
       float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -556,6 +585,13 @@ extern "C" int mpr_conv_set_variant(int narrow, int wide) {
   return 0;
 }
 
+static int g_dgrad_parity = 1;
+extern "C" int mpr_conv_set_dgrad_parity(int on) {
+  const int old = g_dgrad_parity;
+  g_dgrad_parity = on;
+  return old;
+}
+
 static inline void igemm_config(long long M, int Nout, int srcC, int taps, int* mode, int* BM, int* BN) {
   const bool narrow = Nout <= 64;
   if (srcC % 64 == 0 && taps <= 32 && M >= g_dma_min_rows) {
@@ -572,13 +608,29 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   int mode, BM, BN;
   igemm_config(p.M, p.Nout, p.sC, p.R * p.S, &mode, &BM, &BN);
   const bool narrow = BN == 64;
-  // stride-2 data gradients (3/4 of the taps are holes) run better on the deep 256x128 ring
-  const bool s2dgrad = dgrad && mode == 1 && !narrow && (p.sh == 2 || p.sw == 2);
+  // algorithmic flops: a strided data gradient touches each (pixel, tap) pair of the forward conv once
+  const double flops = 2.0 * (double)p.M * (double)p.Nout * (double)p.Kg / (dgrad ? p.sh * p.sw : 1);
+  // stride-2 data gradient on even extents: rows regrouped into the 4 (h mod 2, w mod 2) classes, each padded to
+  // whole tiles, and every tile walks only its class's taps (see the kernel)
+  p.par_rows = 0; p.par_valid = 0;
+  // (a 1x1 filter has a single tap to walk either way; g_dgrad_parity == 2 forces the regrouping for the tests)
+  if (dgrad && mode == 1 && p.sh == 2 && p.sw == 2 && p.Pm % 2 == 0 && p.Qm % 2 == 0 &&
+      (g_dgrad_parity == 2 || (g_dgrad_parity == 1 && p.R * p.S > 1))) {
+    const int B = p.M / (p.Pm * p.Qm);
+    p.Pm /= 2; p.Qm /= 2;
+    p.div_pq = make_fastdiv(p.Pm * p.Qm); p.div_q = make_fastdiv(p.Qm);
+    p.par_valid = B * p.Pm * p.Qm;
+    p.par_rows = ceil_div(p.par_valid, BM) * BM;
+    p.M = 4 * p.par_rows;
+  }
+  // other strided data gradients (3/4 of the taps are holes) run better on the deep 256x128 ring
+  const bool s2dgrad = dgrad && mode == 1 && !narrow && (p.sh == 2 || p.sw == 2) && p.par_rows == 0;
   if (s2dgrad) BM = 256;
   p.ntn = ceil_div(p.Nout, BN);
   const int gm = ceil_div(p.M, BM);
   dim3 grid(gm * p.ntn);
-  void* tok = mpr_prof_begin(dgrad ? 1 : 0, 2.0 * (double)p.M * (double)p.Nout * (double)p.Kg, st);
+  // profiler kinds: 0/1 = LDS-DMA kernel fwd/dgrad (the dominant kernel), 3/4 = register-staged kernel fwd/dgrad
+  void* tok = mpr_prof_begin((mode == 1 ? 0 : 3) + (dgrad ? 1 : 0), flops, st);
   if (mode == 1) {
 #define MPR_DMA(WM_, WN_, ST_, DG_)                                                                   \
   do {                                                                                                \

@@ -487,7 +487,7 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   p.ngroups = p.ntm * nsplit;
   dim3 grid(((p.ngroups + 7) / 8) * 8 * p.ntn);
 #define MPR_WG(WM_, WN_) conv_wgrad_kernel<WM_, WN_><<<grid, 64 * WM_ * WN_, 0, st>>>(p)
-  void* tok = mpr_prof_begin(2, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
+  void* tok = mpr_prof_begin(5, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);   // kind 5: register-staged wgrad
   if (WM == 1 && WN == 1) MPR_WG(1, 1);
   else if (WM == 1 && WN == 2) MPR_WG(1, 2);
   else if (WM == 1 && WN == 3) MPR_WG(1, 3);

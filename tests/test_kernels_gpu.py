@@ -48,6 +48,10 @@ CONV_CASES = [
     (4, 14, 14, 32, 32, 3, 1, 1),
     (2, 9, 11, 32, 64, 3, 2, 1),
     (1, 20, 20, 8, 16, 3, 1, 1),
+    # even extents at stride 2: the data gradient runs as 4 parity classes (ragged class tiles, >1 tile per class)
+    (3, 12, 16, 64, 128, 3, 2, 1),
+    (2, 14, 14, 256, 512, 3, 2, 1),
+    (9, 20, 12, 64, 64, 3, 2, 1),
 ]
 
 
@@ -58,7 +62,9 @@ def igemm_path(request):
     thr = 0 if request.param == 'dma' else 1 << 30
     old = _native.query('mpr_conv_set_dma_min_rows', thr)
     old_w = _native.query('mpr_conv_set_wgrad_dma_min_pixels', thr)
+    old_p = _native.query('mpr_conv_set_dgrad_parity', 2)      # parity classes for 1x1 filters too
     yield request.param
+    _native.query('mpr_conv_set_dgrad_parity', old_p)
     _native.query('mpr_conv_set_dma_min_rows', old)
     _native.query('mpr_conv_set_wgrad_dma_min_pixels', old_w)
 
