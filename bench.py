@@ -36,6 +36,15 @@ def synthetic_batch(B, T, device, seed):
     return {'image': image, 'profile': profile, 'image_shape': image_shape, 'profile_len': profile_len}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (scripts/prof_pmc.sh + scripts/pmc_summary.py run
+    this same command under rocprofv3 --pmc; a process cannot read its own counters), or None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    return round(json.load(open(path))[kernel]['hbm_bytes_per_launch'])
+
+
 def host_cores():
     """CPU share of this process: the cgroup quota when there is one (a 1-GPU box gets 16 of the node's cores)."""
     n = len(os.sched_getaffinity(0))
@@ -152,6 +161,12 @@ def main():
         ms_d, w_d, n_d = collect(1)
         ms_w, w_w, n_w = collect(2)
         ig_ms, ig_w, ig_n = ms_f + ms_d, w_f + w_d, n_f + n_d
+        ig_bytes = ctypes.c_double()
+        lib.mpr_prof_collect_bytes(0, ctypes.byref(ig_bytes))
+        algo_bytes = ig_bytes.value
+        lib.mpr_prof_collect_bytes(1, ctypes.byref(ig_bytes))
+        algo_bytes += ig_bytes.value
+        traffic = pmc_traffic('conv_igemm_dma_kernel')
         achieved = ig_w / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -166,7 +181,10 @@ def main():
                        'loss': round(loss_val, 5)},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma_kernel (forward + data-gradient instantiations, image branch)',
                          'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                         'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, '
+                                                             'profiles/r01_pmc_traffic.json)',
+                         'algorithmic_bytes_per_launch': round(algo_bytes / max(ig_n, 1)),
                          'launches': ig_n, 'avg_launch_us': round(ig_ms * 1e3 / max(ig_n, 1), 2),
                          'share_of_step_time': round(ig_ms / args.steps / ms_per_step, 3),
                          'wgrad_kernel': {'name': 'conv_wgrad_dma_kernel',

@@ -34,6 +34,8 @@ int mpr_device_check(char* name, int name_len);    /* 0 iff device 0 is gfx950; 
 int mpr_prof_enable(int on);
 int mpr_prof_reset(void);
 int mpr_prof_collect(int kind, double* total_ms, double* total_work, int* launches);
+/* algorithmic HBM bytes of the recorded launches of `kind`: operands read once, results written once */
+int mpr_prof_collect_bytes(int kind, double* total_bytes);
 
 /* ---- convolution as implicit GEMM (bf16 MFMA, fp32 accumulate) ------------------------------
  * Stand in for nn.Conv2d inside timm's ResNet (src/image_encoder.py:24) and nn.Conv1d in

@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 extern "C" void mpr_set_error(const char* fmt, ...);
 extern "C" void* mpr_prof_begin(int kind, double work, void* stream);   // no-ops unless mpr_prof_enable(1)
 extern "C" void mpr_prof_end(void* token, void* stream);
+extern "C" void mpr_prof_bytes(void* token, double algorithmic_bytes);
 
 #define MPR_REQUIRE(cond, ...)                  \
   do {                                          \

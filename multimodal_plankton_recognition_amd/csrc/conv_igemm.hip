@@ -610,6 +610,8 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   const bool narrow = BN == 64;
   // algorithmic flops: a strided data gradient touches each (pixel, tap) pair of the forward conv once
   const double flops = 2.0 * (double)p.M * (double)p.Nout * (double)p.Kg / (dgrad ? p.sh * p.sw : 1);
+  // algorithmic HBM bytes: source and weights read once, result written once (+ the fused residual read once)
+  const double algo_bytes = (double)p.src_bytes + 2.0 * p.Nout * p.Kg + 2.0 * (double)p.M * p.Nout * (p.add ? 2 : 1);
   // stride-2 data gradient on even extents: rows regrouped into the 4 (h mod 2, w mod 2) classes, each padded to
   // whole tiles, and every tile walks only its class's taps (see the kernel)
   p.par_rows = 0; p.par_valid = 0;
@@ -631,6 +633,7 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   dim3 grid(gm * p.ntn);
   // profiler kinds: 0/1 = LDS-DMA kernel fwd/dgrad (the dominant kernel), 3/4 = register-staged kernel fwd/dgrad
   void* tok = mpr_prof_begin((mode == 1 ? 0 : 3) + (dgrad ? 1 : 0), flops, st);
+  mpr_prof_bytes(tok, algo_bytes);
   if (mode == 1) {
 #define MPR_DMA(WM_, WN_, ST_, DG_)                                                                   \
   do {                                                                                                \

@@ -442,6 +442,7 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
     p.ngroups = p.ntm * nsplit;
   dim3 grid(((p.ngroups + 7) / 8) * 8 * p.ntn);
     void* tok = mpr_prof_begin(2, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
+    mpr_prof_bytes(tok, (double)p.x_bytes + (double)p.dy_bytes + 4.0 * K * p.Ng);   // x, dy read once; dw written once
 #define MPR_WGD(WM_, WN_)                                                                             \
   do {                                                                                                \
     const size_t smem_ = (size_t)2 * 64 * (128 * WM_ + 128 * WN_);                             \

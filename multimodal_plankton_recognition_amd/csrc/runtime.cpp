@@ -12,7 +12,7 @@ static thread_local char g_err[512] = "";
 
 struct ProfRec {
   int kind;
-  double work;
+  double work, bytes;
   hipEvent_t a, b;
 };
 static bool g_prof_on = false;
@@ -90,6 +90,7 @@ void* mpr_prof_begin(int kind, double work, void* stream) {
   ProfRec r;
   r.kind = kind;
   r.work = work;
+  r.bytes = 0.0;
   r.a = prof_event();
   r.b = prof_event();
   hipEventRecord(r.a, (hipStream_t)stream);
@@ -101,6 +102,19 @@ void mpr_prof_end(void* token, void* stream) {
   if (!token) return;
   ProfRec& r = g_prof[(size_t)(uintptr_t)token - 1];
   hipEventRecord(r.b, (hipStream_t)stream);
+}
+
+// internal: algorithmic HBM bytes (operands read once + results written once) of the launch behind `token`
+void mpr_prof_bytes(void* token, double bytes) {
+  if (token) g_prof[(size_t)(uintptr_t)token - 1].bytes = bytes;
+}
+
+int mpr_prof_collect_bytes(int kind, double* total_bytes) {
+  double b = 0.0;
+  for (auto& r : g_prof)
+    if (kind < 0 || r.kind == kind) b += r.bytes;
+  if (total_bytes) *total_bytes = b;
+  return 0;
 }
 
 // Sums over all recorded launches of `kind` (-1: every kind).  Synchronises on the recorded events.
