@@ -203,9 +203,16 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int i = pl; i < nparts; i += 32) {
-      s1 += (double)partials[((size_t)i * 2) * C + c];
-      s2 += (double)partials[((size_t)i * 2 + 1) * C + c];
+    for (int i0 = pl; i0 < nparts; i0 += 32 * 8) {   // 16 independent loads in flight (the chain is latency-bound)
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 32 * u;
+        a[u] = i < nparts ? partials[((size_t)i * 2) * C + c] : 0.f;
+        b[u] = i < nparts ? partials[((size_t)i * 2 + 1) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
     }
   red[0][pl][threadIdx.x & 31] = s1;
   red[1][pl][threadIdx.x & 31] = s2;
