@@ -43,6 +43,13 @@ int mpr_prof_collect_bytes(int kind, double* total_bytes);
 int mpr_conv_packed_sizes(int K, int C, int R, int S, long long* fwd_elems, long long* dgrad_elems);
 int mpr_conv_pack_weights(const float* w_oihw, void* w_fwd, void* w_dgrad /* may be NULL */, int K, int C, int R,
                           int S, void* stream);
+/* the same for a filter of logical shape [K,C,R,S] and element strides (sk, sc, sr, ss): e.g. the [K][R][S][C]
+ * memory of a channels-last weight */
+int mpr_conv_pack_weights_strided(const float* w, long long sk, long long sc, long long sr, long long ss, void* w_fwd,
+                                  void* w_dgrad /* may be NULL */, int K, int C, int R, int S, void* stream);
+/* every filter of a model in ONE launch (after the optimizer step): `table` = n device rows of 12 int64
+ * {w, w_fwd, w_dgrad (0: none), K, C, R, S, sk, sc, sr, ss, 0} */
+int mpr_conv_pack_weights_multi(const void* table, int n, void* stream);
 int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S);
 /* rows (B*P*Q) from which the LDS-DMA ring kernel replaces the register-staged one (default 16384);
  * returns the previous threshold */
@@ -58,7 +65,10 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may 
                  int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
 int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add /* may be NULL */, int B, int H,
                    int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
-int mpr_conv_wgrad(const void* x, const void* dy, float* workspace /* K*R*S*C floats */, float* dw_oihw,
+/* dw_oihw != NULL: workspace is zeroed, filled as [K][R][S][C] and permuted into (accumulate: added to) dw_oihw.
+ * dw_oihw == NULL: the gradient stays in `workspace` as [K][R][S][C] -- the memory of a channels-last weight's
+ * gradient -- zeroed first unless `accumulate` (then the split-K atomics add into what is there) */
+int mpr_conv_wgrad(const void* x, const void* dy, float* workspace /* K*R*S*C floats */, float* dw_oihw /* may be NULL */,
                    int accumulate, int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph,
                    int pw, void* stream);
 

@@ -82,26 +82,52 @@ def last_error():
     return lib().mpr_last_error().decode()
 
 
+def is_dense(t):
+    """Every element of the spanned storage used exactly once: a contiguous tensor or any permutation of one
+    (e.g. a channels-last conv weight, whose [K][R][S][C] memory the conv kernels address through strides)."""
+    if t.is_contiguous() or t.numel() <= 1:
+        return True
+    expect = 1
+    for st, sz in sorted((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1):
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
 def ptr(t):
-    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    """Device pointer of a dense CUDA/HIP tensor (None -> NULL)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise NativeLibraryError('HIP kernels need device tensors (got a CPU tensor); there is no CPU fallback')
-    if not t.is_contiguous():
+    if not is_dense(t):
         raise NativeLibraryError('HIP kernels need contiguous tensors')
     return t.data_ptr()
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+def stream(device_index=None):
+    """Raw hipStream_t of torch's current stream (the C-level getter: the Python Stream object costs ~8 us)."""
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(device_index)
 
 
 def call(name, *args):
     """Invoke an int-returning entry point on the current stream; tensors become device pointers."""
     fn = getattr(lib(), name)
-    conv = [ptr(a) if (a is None or torch.is_tensor(a)) else a for a in args]
-    rc = fn(*conv, stream())
+    conv = []
+    dev = None
+    for a in args:
+        if a is None:
+            conv.append(None)
+        elif torch.is_tensor(a):
+            conv.append(ptr(a))
+            if dev is None:
+                dev = a.device.index
+        else:
+            conv.append(a)
+    rc = fn(*conv, stream(dev))
     if rc != 0:
         raise NativeLibraryError(f'{name} failed (rc={rc}): {last_error()}')
 

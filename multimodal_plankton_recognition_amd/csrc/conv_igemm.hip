@@ -514,31 +514,49 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight packing:  OIHW fp32  ->  Wf [Kpad128][ceil64(R*S*C)]  and  Wd [Cpad128][ceil64(R*S*K)]  bf16
-__global__ void conv_pack_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf,
-                                         bf16_t* __restrict__ wd, int K, int C, int R, int S,
-                                         int KgF, int KgFpad, int NpadF, int KgD, int KgDpad, int NpadD) {
-  const int totalF = NpadF * KgFpad, totalD = wd ? NpadD * KgDpad : 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < totalF + totalD; i += gridDim.x * blockDim.x) {
+// weight packing:  fp32 filter (any dense layout, given by its element strides: OIHW or the [K][R][S][C] memory of
+// a channels-last weight)  ->  Wf [Kpad128][ceil64(R*S*C)]  and  Wd [Cpad128][ceil64(R*S*K)]  bf16
+struct PackEntry {            // 12 x int64: one row of the table of mpr_conv_pack_weights_multi
+  const float* w;
+  bf16_t* wf;
+  bf16_t* wd;                 // may be NULL
+  long long K, C, R, S, sk, sc, sr, ss, pad_;
+};
+
+__device__ __forceinline__ void pack_one(const PackEntry& e, int first, int step) {
+  const int K = (int)e.K, C = (int)e.C, R = (int)e.R, S = (int)e.S;
+  const int KgF = R * S * C, KgD = R * S * K;
+  const int KgFpad = (KgF + 63) / 64 * 64, KgDpad = (KgD + 63) / 64 * 64;
+  const int totalF = ((K + 127) / 128 * 128) * KgFpad, totalD = e.wd ? ((C + 127) / 128 * 128) * KgDpad : 0;
+  for (int i = first; i < totalF + totalD; i += step) {
     if (i < totalF) {
       const int k = i / KgFpad, g = i - k * KgFpad;
       float v = 0.f;
       if (k < K && g < KgF) {
         const int t = g / C, c = g - t * C, r = t / S, s = t - r * S;
-        v = w[((size_t)(k * C + c) * R + r) * S + s];
+        v = e.w[k * e.sk + c * e.sc + r * e.sr + s * e.ss];
       }
-      wf[i] = (bf16_t)v;
+      e.wf[i] = (bf16_t)v;
     } else {
       const int j = i - totalF;
       const int c = j / KgDpad, g = j - c * KgDpad;
       float v = 0.f;
       if (c < C && g < KgD) {
         const int t = g / K, k = g - t * K, r = t / S, s = t - r * S;
-        v = w[((size_t)(k * C + c) * R + r) * S + s];
+        v = e.w[k * e.sk + c * e.sc + r * e.sr + s * e.ss];
       }
-      wd[j] = (bf16_t)v;
+      e.wd[j] = (bf16_t)v;
     }
   }
+}
+
+__global__ void conv_pack_weights_kernel(const PackEntry e) {
+  pack_one(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+__global__ void conv_pack_weights_multi_kernel(const PackEntry* __restrict__ table) {
+  const PackEntry e = table[blockIdx.y];
+  pack_one(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 static inline int pad_to(int x, int a) { return (x + a - 1) / a * a; }
@@ -552,16 +570,32 @@ int mpr_conv_packed_sizes(int K, int C, int R, int S, long long* fwd_elems, long
   return MPR_OK;
 }
 
-int mpr_conv_pack_weights(const float* w_oihw, void* w_fwd, void* w_dgrad, int K, int C, int R, int S,
-                          void* stream) {
-  MPR_REQUIRE(w_oihw && w_fwd, "mpr_conv_pack_weights: null pointer");
+// w: logical [K,C,R,S] with element strides (sk, sc, sr, ss)
+int mpr_conv_pack_weights_strided(const float* w, long long sk, long long sc, long long sr, long long ss, void* w_fwd,
+                                  void* w_dgrad, int K, int C, int R, int S, void* stream) {
+  MPR_REQUIRE(w && w_fwd, "mpr_conv_pack_weights: null pointer");
   const int KgF = R * S * C, KgD = R * S * K;
   const int total = pad_to(K, 128) * pad_to(KgF, 64) + (w_dgrad ? pad_to(C, 128) * pad_to(KgD, 64) : 0);
   const int grid = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
-  conv_pack_weights_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
-      w_oihw, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, K, C, R, S, KgF, pad_to(KgF, 64), pad_to(K, 128), KgD,
-      pad_to(KgD, 64), pad_to(C, 128));
+  PackEntry e{w, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, K, C, R, S, sk, sc, sr, ss, 0};
+  conv_pack_weights_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(e);
   MPR_LAUNCH_CHECK("conv_pack_weights_kernel");
+  return MPR_OK;
+}
+
+int mpr_conv_pack_weights(const float* w_oihw, void* w_fwd, void* w_dgrad, int K, int C, int R, int S,
+                          void* stream) {
+  return mpr_conv_pack_weights_strided(w_oihw, (long long)C * R * S, (long long)R * S, S, 1, w_fwd, w_dgrad, K, C, R,
+                                       S, stream);
+}
+
+// table: n rows of 12 int64 on the device: {w, w_fwd, w_dgrad (0 = none), K, C, R, S, sk, sc, sr, ss, 0}.
+// One launch repacks every filter of a model after the optimizer step.
+int mpr_conv_pack_weights_multi(const void* table, int n, void* stream) {
+  MPR_REQUIRE(table && n > 0, "mpr_conv_pack_weights_multi: empty table");
+  static_assert(sizeof(PackEntry) == 12 * 8, "PackEntry must be 12 x int64");
+  conv_pack_weights_multi_kernel<<<dim3(128, n), 256, 0, (hipStream_t)stream>>>((const PackEntry*)table);
+  MPR_LAUNCH_CHECK("conv_pack_weights_multi_kernel");
   return MPR_OK;
 }
 

@@ -406,9 +406,10 @@ int mpr_conv_set_wgrad_dma_min_pixels(int pixels) {   // tuning / test knob; ret
 }
 
 // dw_oihw[K,C,R,S] (fp32) = sum over the batch;  workspace: K*R*S*C floats (zeroed here).
+// dw_oihw may be NULL: see below.
 int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oihw, int accumulate, int B,
                    int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
-  MPR_REQUIRE(x && dy && workspace && dw_oihw, "mpr_conv_wgrad: null pointer");
+  MPR_REQUIRE(x && dy && workspace, "mpr_conv_wgrad: null pointer");
   MPR_REQUIRE(C % 8 == 0 && K % 8 == 0, "mpr_conv_wgrad: C (%d) and K (%d) must be multiples of 8", C, K);
   const int P = (H + 2 * ph - R) / sh + 1, Q = (W + 2 * pw - S) / sw + 1;
   MPR_REQUIRE(P > 0 && Q > 0, "mpr_conv_wgrad: empty output");
@@ -424,7 +425,9 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   for (int r = 0; r < R && r * S < 32; ++r) p.rowpat |= 1u << (r * S);
   p.x_bytes = (unsigned)((size_t)B * H * W * C * 2);
   p.dy_bytes = (unsigned)((size_t)B * P * Q * K * 2);
-  MPR_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)K * p.Ng, st));
+  // dw_oihw == NULL: the gradient stays in `workspace` as [K][R][S][C] (the physical layout of a channels-last
+  // weight); `accumulate` then adds into what is there instead of zeroing it first
+  if (dw_oihw || !accumulate) MPR_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)K * p.Ng, st));
 
   if (C % 64 == 0 && K % 64 == 0 && R * S <= 31 && p.Mpix >= g_wgrad_dma_min_pix) {
     // LDS-DMA ring kernel: 64-pixel chunks, 2 workgroups per CU
@@ -465,8 +468,10 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
     MPR_LAUNCH_CHECK("conv_wgrad_dma_kernel");
     const int total = K * C * R * S;
     const int g2 = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
-    wgrad_unpack_kernel<<<g2, 256, 0, st>>>(workspace, dw_oihw, K, C, R, S, accumulate);
-    MPR_LAUNCH_CHECK("wgrad_unpack_kernel");
+    if (dw_oihw) {
+      wgrad_unpack_kernel<<<g2, 256, 0, st>>>(workspace, dw_oihw, K, C, R, S, accumulate);
+      MPR_LAUNCH_CHECK("wgrad_unpack_kernel");
+    }
     return MPR_OK;
   }
 
@@ -500,8 +505,10 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   MPR_LAUNCH_CHECK("conv_wgrad_kernel");
   const int total = K * C * R * S;
   const int g2 = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
-  wgrad_unpack_kernel<<<g2, 256, 0, st>>>(workspace, dw_oihw, K, C, R, S, accumulate);
-  MPR_LAUNCH_CHECK("wgrad_unpack_kernel");
+  if (dw_oihw) {
+    wgrad_unpack_kernel<<<g2, 256, 0, st>>>(workspace, dw_oihw, K, C, R, S, accumulate);
+    MPR_LAUNCH_CHECK("wgrad_unpack_kernel");
+  }
   return MPR_OK;
 }
 

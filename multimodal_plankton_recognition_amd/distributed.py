@@ -185,13 +185,22 @@ class DataParallelStep:
         loss, d_img, d_prof, dls = dp_clip(emb['image_emb'], emb['profile_emb'], model.loss.logit_scale,
                                            self.comm, self.math)
         torch.autograd.backward([emb['image_emb'], emb['profile_emb']], [d_img, d_prof])
-        model.loss.logit_scale.grad = dls
-        flat, views = self._flat_views()
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(views, grads)
-        self.comm.all_reduce_sum(flat)
-        for p, v in zip(self.params, views):
-            p.grad = v
+        ls = model.loss.logit_scale
+        arena = getattr(self.opt, 'flat_grad', None)
+        if arena is not None and getattr(ls, '_mpr_grad', None) is ls.grad:
+            # FusedSGD: every gradient already sits in the optimizer's flat buffer (the fused backward Functions
+            # accumulate into it) -- ONE all-reduce of that buffer, no gather copies
+            ls.grad.add_(dls.reshape(ls.shape))
+            ls._mpr_touched = True
+            self.comm.all_reduce_sum(arena)
+        else:
+            ls.grad = dls
+            flat, views = self._flat_views()
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+            torch._foreach_copy_(views, grads)
+            self.comm.all_reduce_sum(flat)
+            for p, v in zip(self.params, views):
+                p.grad = v
         self.opt.step()
         model.train_loss.append(loss.detach())
         return loss

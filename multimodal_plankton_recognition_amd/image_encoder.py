@@ -15,7 +15,7 @@ import torch
 from torch import Tensor, nn
 
 from .layers import BasicBlock, BatchNormParams, PoolTailFn, StemFn
-from .ops import ConvGeom
+from .ops import ConvGeom, to_krsc_
 
 _RESNETS = {'resnet10t': None, 'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3), 'resnet14': (1, 2, 2, 1),
             'resnet10': (1, 1, 1, 1)}
@@ -45,6 +45,7 @@ class ResNetBackbone(nn.Module):
             for m in self.modules():
                 if isinstance(m, BasicBlock):
                     nn.init.zeros_(m.bn2.weight)
+        to_krsc_(self)          # block filters: [K][R][S][C] memory (state_dict / logical shapes unchanged)
 
     def forward_features(self, image: Tensor) -> Tensor:
         """fp32 [B, in_chans, H, W] -> channels-last bf16 [B, H/32, W/32, 512]."""

@@ -85,7 +85,7 @@ class StemFn(torch.autograd.Function):
         st = _bn_coefs(stats, _rows(y), mod.bn1, train)
         pooled, idx = ops.bn_relu_maxpool_fwd(y, st)
         if train:
-            ctx.save_for_backward(x, y, idx, conv_w, bn_w)
+            ctx.save_for_backward(x, y, idx, conv_w, bn_w, bn_b)
             ctx.st, ctx.g, ctx.s2d = st, g, s2d
         ctx.train = train
         return pooled
@@ -94,12 +94,14 @@ class StemFn(torch.autograd.Function):
     def backward(ctx, dpooled):
         if not ctx.train:
             raise RuntimeError('backward through an eval-mode BatchNorm stem is not implemented')
-        x, y, idx, conv_w, bn_w = ctx.saved_tensors
-        dx, dgamma, dbeta = ops.pool_bn_bwd(dpooled.contiguous(), idx, y, bn_w, ctx.st)
+        x, y, idx, conv_w, bn_w, bn_b = ctx.saved_tensors
+        # parameter gradients go straight into the optimizer's flat buffer when it owns one (ops.grad_target):
+        # the corresponding return values are then None
+        dx, dgamma, dbeta = ops.pool_bn_bwd(dpooled.contiguous(), idx, y, bn_w, ctx.st, beta=bn_b)
         if ctx.s2d:
-            dw = ops.stem_s2d_wgrad(x, dx, ctx.g, conv_w.shape)
+            dw = ops.stem_s2d_wgrad(x, dx, ctx.g, conv_w)
         else:
-            dw = ops.stem_wgrad(x, dx, ctx.g, conv_w.shape)
+            dw = ops.stem_wgrad(x, dx, ctx.g, conv_w)
         return None, dw, dgamma, dbeta, None
 
 
@@ -131,7 +133,7 @@ class BasicBlockFn(torch.autograd.Function):
         out = ops.bn_apply(x2, st2, identity, True)
         ctx.train = train
         if train:
-            ctx.save_for_backward(x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd)
+            ctx.save_for_backward(x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd, b1, b2, bd)
             ctx.misc = (st1, st2, std, c1, c2, cd, wd1, wd2, wdd)
         return out
 
@@ -139,20 +141,20 @@ class BasicBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         if not ctx.train:
             raise RuntimeError('backward through an eval-mode BatchNorm block is not implemented')
-        x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd = ctx.saved_tensors
+        x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd, b1, b2, bd = ctx.saved_tensors
         st1, st2, std, c1, c2, cd, wd1, wd2, wdd = ctx.misc
         dout = dout.contiguous()
         # out = relu(bn2(x2) + identity):  dz = dout * (out > 0) feeds bn2 AND the shortcut
-        dx2, dg2, db2, dz = ops.bn_bwd(dout, out, x2, g2, st2, MASK_Y, want_dz=True)
-        dw2 = ops.conv_wgrad(a1, dx2, c2, w2.shape)
+        dx2, dg2, db2, dz = ops.bn_bwd(dout, out, x2, g2, st2, MASK_Y, want_dz=True, beta=b2)
+        dw2 = ops.conv_wgrad(a1, dx2, c2, w2)
         da1 = ops.conv_dgrad(dx2, wd2, c2, a1.shape)
         # a1 = bf16(relu(x1*scale+shift)) has no residual: its ReLU mask is recomputed from x1 (bit-identical to
         # a1 > 0) instead of re-reading a1 in both backward passes
-        dx1, dg1, db1, _ = ops.bn_bwd(da1, None, x1, g1, st1, MASK_RECOMPUTE)
-        dw1 = ops.conv_wgrad(x, dx1, c1, w1.shape)
+        dx1, dg1, db1, _ = ops.bn_bwd(da1, None, x1, g1, st1, MASK_RECOMPUTE, beta=b1)
+        dw1 = ops.conv_wgrad(x, dx1, c1, w1)
         if wd is not None:
-            dxd, dgd, dbd, _ = ops.bn_bwd(dz, None, xd, gd, std, MASK_NONE)
-            dwd = ops.conv_wgrad(x, dxd, cd, wd.shape)
+            dxd, dgd, dbd, _ = ops.bn_bwd(dz, None, xd, gd, std, MASK_NONE, beta=bd)
+            dwd = ops.conv_wgrad(x, dxd, cd, wd)
             skip = ops.conv_dgrad(dxd, wdd, cd, x.shape)
         else:
             dgd = dbd = dwd = None

@@ -47,8 +47,67 @@ class ConvGeom:
 _pack_cache = {}
 
 
+def _kcrs_strides(weight):
+    """Element strides (sk, sc, sr, ss) of a conv weight viewed as [K, C, R, S] (Conv1d: R == 1)."""
+    st = weight.stride()
+    return (st[0], st[1], 0, st[2]) if weight.dim() == 3 else tuple(st)
+
+
+def is_krsc(weight):
+    """True when the weight's MEMORY is [K][R][S][C] (channels-last): what conv_wgrad produces natively."""
+    if weight.dim() == 3:
+        K, C, S = weight.shape
+        return tuple(weight.stride()) == (S * C, 1, C)
+    K, C, R, S = weight.shape
+    return tuple(weight.stride()) == (R * S * C, 1, S * C, C)
+
+
+def to_krsc_(module):
+    """Re-lay every Conv1d/Conv2d weight under `module` as [K][R][S][C] in memory (logical shape, values and
+    state_dict unchanged): the weight gradient then needs no permute and the bf16 panels are a plain cast."""
+    for m in module.modules():
+        if isinstance(m, (torch.nn.Conv1d, torch.nn.Conv2d)) and m.weight.shape[1] % 8 == 0:
+            w = m.weight.data
+            perm = (0, 2, 1) if w.dim() == 3 else (0, 2, 3, 1)
+            inv = (0, 2, 1) if w.dim() == 3 else (0, 3, 1, 2)
+            m.weight.data = w.permute(*perm).contiguous().permute(*inv)
+    return module
+
+
+class _PackRegistry:
+    """All filters that have bf16 panels: lets the optimizer refresh every panel in ONE launch after its step."""
+
+    def __init__(self):
+        self.entries = []        # [weakref(weight), data_ptr, wf, wd, geom]
+        self.table = None
+
+    def add(self, weight, wf, wd, geom):
+        import weakref
+        self.entries = [e for e in self.entries if e[0]() is not None and e[0]() is not weight]
+        self.entries.append([weakref.ref(weight), weight.data_ptr(), wf, wd, geom])
+        self.table = None
+
+    def repack_all(self):
+        live = [e for e in self.entries if e[0]() is not None and e[0]().data_ptr() == e[1]]
+        if len(live) != len(self.entries):
+            self.entries, self.table = live, None
+        if not live:
+            return
+        if self.table is None:
+            rows = [[e[1], e[2].data_ptr(), e[3].data_ptr() if e[3] is not None else 0, e[4].K, e[4].C, e[4].R, e[4].S,
+                     *_kcrs_strides(e[0]()), 0] for e in live]
+            self.table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(live[0][2].device, non_blocking=True)
+        N.call('mpr_conv_pack_weights_multi', self.table, len(live))
+        for e in live:
+            w = e[0]()
+            w._mpr_packed = ((w.data_ptr(), w._version), e[2], e[3])
+
+
+pack_registry = _PackRegistry()
+
+
 def packed_weights(weight, geom, need_dgrad=True):
-    """bf16 GEMM panels of an fp32 OIHW weight, cached on (storage, version)."""
+    """bf16 GEMM panels of an fp32 conv weight (any dense layout), cached on (storage, version)."""
     # the cache entry lives ON the tensor object (dies with it: no id()/address aliasing between tensors)
     key = (weight.data_ptr(), weight._version)
     hit = getattr(weight, '_mpr_packed', None)
@@ -56,11 +115,25 @@ def packed_weights(weight, geom, need_dgrad=True):
         return hit[1], hit[2]
     nf = (geom.K + 127) // 128 * 128 * ((geom.R * geom.S * geom.C + 63) // 64 * 64)
     nd = (geom.C + 127) // 128 * 128 * ((geom.R * geom.S * geom.K + 63) // 64 * 64)
-    wf = torch.empty(nf, dtype=BF16, device=weight.device)
-    wd = torch.empty(nd, dtype=BF16, device=weight.device) if need_dgrad else None
-    N.call('mpr_conv_pack_weights', weight.detach(), wf, wd, geom.K, geom.C, geom.R, geom.S)
+    # keep the panel buffers of an earlier pack (stable pointers for the registry's table)
+    wf = hit[1] if hit is not None and hit[0][0] == key[0] else torch.empty(nf, dtype=BF16, device=weight.device)
+    wd = hit[2] if hit is not None and hit[0][0] == key[0] and hit[2] is not None else (
+        torch.empty(nd, dtype=BF16, device=weight.device) if need_dgrad else None)
+    N.call('mpr_conv_pack_weights_strided', weight.detach(), *_kcrs_strides(weight), wf, wd, geom.K, geom.C, geom.R,
+           geom.S)
+    if hit is None or hit[1] is not wf or hit[2] is not wd:
+        pack_registry.add(weight, wf, wd, geom)
     weight._mpr_packed = (key, wf, wd)
     return wf, wd
+
+
+def grad_target(param):
+    """The optimizer-owned gradient memory of `param` (FusedSGD: a view of its flat buffer with the parameter's
+    strides, zeroed by zero_grad) or None.  A backward that finds one ACCUMULATES into it and hands autograd None."""
+    tgt = getattr(param, '_mpr_grad', None) if torch.is_tensor(param) else None
+    if tgt is not None:
+        param._mpr_touched = True
+    return tgt
 
 
 # ------------------------------------------------------------------------------------------ conv
@@ -84,10 +157,28 @@ def conv_dgrad(dy, wd, g, x_shape, add=None):
     return dx
 
 
-def conv_wgrad(x, dy, g, weight_shape):
+def conv_wgrad(x, dy, g, weight):
+    """Gradient of `weight` (a tensor: its layout and, if the optimizer installed one, its gradient memory are
+    used; or a plain shape -> contiguous OIHW result).  Returns None when it accumulated into grad_target(weight)."""
     B, H, W, C = _geom(x)
+    if not torch.is_tensor(weight):
+        ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
+        dw = torch.empty(weight, dtype=F32, device=x.device)
+        N.call('mpr_conv_wgrad', x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail)
+        return dw
+    tgt = grad_target(weight)
+    if is_krsc(weight):          # the kernel's native [K][R][S][C] result IS the gradient's memory
+        if tgt is not None:
+            N.call('mpr_conv_wgrad', x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail)
+            return None
+        dw = torch.empty_strided(weight.shape, weight.stride(), dtype=F32, device=x.device)
+        N.call('mpr_conv_wgrad', x, dy, dw, None, 0, B, H, W, C, g.K, *g.tail)
+        return dw
     ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
-    dw = torch.empty(weight_shape, dtype=F32, device=x.device)
+    if tgt is not None and tgt.is_contiguous():
+        N.call('mpr_conv_wgrad', x, dy, ws, tgt, 1, B, H, W, C, g.K, *g.tail)
+        return None
+    dw = torch.empty(weight.shape, dtype=F32, device=x.device)
     N.call('mpr_conv_wgrad', x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail)
     return dw
 
@@ -116,24 +207,35 @@ def stem_s2d_operands(x, weight):
     key = (weight.data_ptr(), weight._version)
     hit = getattr(weight, '_mpr_s2d', None)
     if hit is None or hit[0] != key:
-        w2 = torch.empty(K, 8, 4, 4, dtype=F32, device=x.device)
+        # (buffers persist across steps; the panel is packed here directly -- the temporary filter must not enter
+        # the optimizer's repack registry)
+        w2 = hit[2] if hit is not None else torch.empty(K, 8, 4, 4, dtype=F32, device=x.device)
+        wf2 = hit[1] if hit is not None else torch.empty((K + 127) // 128 * 128 * 128, dtype=BF16, device=x.device)
         N.call('mpr_stem_w_s2d', weight.detach(), w2, K)
-        wf2, _ = packed_weights(w2, g2, need_dgrad=False)
-        weight._mpr_s2d = (key, wf2)
+        N.call('mpr_conv_pack_weights', w2, wf2, None, K, 8, 4, 4)
+        weight._mpr_s2d = (key, wf2, w2)
         hit = weight._mpr_s2d
     return xs, g2, hit[1]
 
 
-def stem_s2d_wgrad(xs, dy, g2, weight_shape):
+def stem_s2d_wgrad(xs, dy, g2, weight):
     dw2 = conv_wgrad(xs, dy, g2, (g2.K, 8, 4, 4))
-    dw = torch.empty(weight_shape, dtype=F32, device=xs.device)
+    tgt = grad_target(weight)
+    if tgt is not None and tgt.is_contiguous():
+        N.call('mpr_stem_dw_gather', dw2, tgt, g2.K, 1)
+        return None
+    dw = torch.empty(weight.shape if torch.is_tensor(weight) else weight, dtype=F32, device=xs.device)
     N.call('mpr_stem_dw_gather', dw2, dw, g2.K, 0)
     return dw
 
 
-def stem_wgrad(x, dy, g, weight_shape):
+def stem_wgrad(x, dy, g, weight):
     B, H, W, C = _geom(x)
-    dw = torch.empty(weight_shape, dtype=F32, device=x.device)
+    tgt = grad_target(weight)
+    if tgt is not None and tgt.is_contiguous():
+        N.call('mpr_stem_wgrad', x, dy, tgt, 1, B, H, W, C, g.K, *g.tail)
+        return None
+    dw = torch.empty(weight.shape if torch.is_tensor(weight) else weight, dtype=F32, device=x.device)
     N.call('mpr_stem_wgrad', x, dy, dw, 0, B, H, W, C, g.K, *g.tail)
     return dw
 
@@ -189,23 +291,30 @@ def bn_apply(x, st, residual=None, relu=True):
 MASK_NONE, MASK_Y, MASK_RECOMPUTE = 0, 1, 2
 
 
-def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False):
-    """-> dx (bf16), dgamma, dbeta (fp32), dz (bf16 | None)."""
+def _bn_grad_targets(gamma, beta, C, dev):
+    """(dgamma, dbeta, accumulate, handed_to_autograd?) -- the optimizer's gradient memory when both have one."""
+    tg, tb = grad_target(gamma), grad_target(beta)
+    if tg is not None and tb is not None:
+        return tg, tb, 1, False
+    return torch.empty(C, dtype=F32, device=dev), torch.empty(C, dtype=F32, device=dev), 0, True
+
+
+def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False, beta=None):
+    """-> dx (bf16), dgamma, dbeta (fp32; None when accumulated into the optimizer's buffers), dz (bf16 | None)."""
     C = x.shape[-1]
     rows = x.numel() // C
     dev = x.device
     parts = torch.empty(N.query('mpr_bn_reduce_rows', rows, C), 2, C, dtype=F32, device=dev)
     N.call('mpr_bn_bwd_reduce', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, rows, C)
     parts = _prereduce(parts)
-    dgamma = torch.empty(C, dtype=F32, device=dev)
-    dbeta = torch.empty(C, dtype=F32, device=dev)
+    dgamma, dbeta, acc, ret = _bn_grad_targets(gamma, beta, C, dev)
     coef = torch.empty(3, C, dtype=F32, device=dev)
-    N.call('mpr_bn_bwd_finalize', parts, parts.shape[0], rows, gamma.detach(), st.mean, st.invstd, dgamma, dbeta, 0,
+    N.call('mpr_bn_bwd_finalize', parts, parts.shape[0], rows, gamma.detach(), st.mean, st.invstd, dgamma, dbeta, acc,
            coef, C)
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
     N.call('mpr_bn_bwd_apply', dy, y, x, coef, st.scale, st.shift, mask_mode, dx, dz, rows, C)
-    return dx, dgamma, dbeta, dz
+    return dx, (dgamma if ret else None), (dbeta if ret else None), dz
 
 
 # ------------------------------------------------------------------------------------------ pooling
@@ -233,7 +342,7 @@ def maxpool_bwd(dy, idx, x_shape, k=3, s=2, p=1):
     return dx
 
 
-def pool_bn_bwd(dpooled, idx, x, gamma, st, k=3, s=2, p=1):
+def pool_bn_bwd(dpooled, idx, x, gamma, st, k=3, s=2, p=1, beta=None):
     """Stem backward, fused: maxpool-backward gather + ReLU mask + BatchNorm backward.  -> dx, dgamma, dbeta."""
     B, H, W, C, RH, RW, SH, SW, PH, PW = _pool_geom(x, k, s, p)
     dev = x.device
@@ -242,14 +351,13 @@ def pool_bn_bwd(dpooled, idx, x, gamma, st, k=3, s=2, p=1):
     geo = (B, H, W, C, RH, RW, SH, SW, PH, PW)
     N.call('mpr_pool_bn_bwd', 0, dpooled, idx, x, st.scale, st.shift, st.mean, st.invstd, None, parts, None, *geo)
     parts = _prereduce(parts)
-    dgamma = torch.empty(C, dtype=F32, device=dev)
-    dbeta = torch.empty(C, dtype=F32, device=dev)
+    dgamma, dbeta, acc, ret = _bn_grad_targets(gamma, beta, C, dev)
     coef = torch.empty(3, C, dtype=F32, device=dev)
-    N.call('mpr_bn_bwd_finalize', parts, parts.shape[0], rows, gamma.detach(), st.mean, st.invstd, dgamma, dbeta, 0,
+    N.call('mpr_bn_bwd_finalize', parts, parts.shape[0], rows, gamma.detach(), st.mean, st.invstd, dgamma, dbeta, acc,
            coef, C)
     dx = torch.empty_like(x)
     N.call('mpr_pool_bn_bwd', 1, dpooled, idx, x, st.scale, st.shift, None, None, coef, None, dx, *geo)
-    return dx, dgamma, dbeta
+    return dx, (dgamma if ret else None), (dbeta if ret else None)
 
 
 def global_pool_fwd(x, mode):
@@ -331,8 +439,33 @@ def scale_by_scalar(x, s):
 
 
 # ------------------------------------------------------------------------------------------ optimiser
+def _mark_touched(p):
+    p._mpr_touched = True
+
+
+def _dense(t):
+    """Every element of the storage span used exactly once (any permutation of a contiguous tensor)."""
+    if t.numel() <= 1:
+        return True
+    dims = sorted(((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1))
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
 class FusedSGD:
-    """torch.optim.SGD semantics (src/model.py:147-148) as ONE multi-tensor launch per step."""
+    """torch.optim.SGD semantics (src/model.py:147-148) as ONE multi-tensor launch per step.
+
+    Gradients and momentum live in two flat fp32 buffers owned by the optimizer: ``p.grad`` is a view of
+    ``flat_grad`` with the parameter's own strides (so a channels-last conv weight receives the weight-gradient
+    kernel's native [K][R][S][C] result in place), ``zero_grad`` is one memset, the fused backward Functions
+    accumulate straight into it (``ops.grad_target``), data-parallel training all-reduces ``flat_grad`` as it is,
+    and the pointer table of the update kernel is built once.  A gradient assigned from outside
+    (``p.grad = t``) is copied in; a parameter whose gradient is None or was never produced since ``zero_grad``
+    is skipped, as torch does."""
 
     def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
         self.params = [p for p in params if p.requires_grad]
@@ -340,54 +473,96 @@ class FusedSGD:
         self.weight_decay, self.nesterov = float(weight_decay), bool(nesterov)
         self.bufs = {}
         self.steps = 0
-        self._table_key = None
-        self._table = None
-        self._pinned = None
-        self._table_dev = None
+        self.flat_grad = self.flat_buf = None
+        self._views = None
+        self._arena_key = None
+        self._table_full = None
+        self._seen = set()        # ids of parameters that have taken a step (momentum buffer initialised)
+
+    # ------------------------------------------------------------------ flat buffers
+    def _install(self):
+        ps = self.params
+        key = tuple(p.data_ptr() for p in ps)
+        if key == self._arena_key:
+            return
+        dev = ps[0].device
+        offs, total = [], 0
+        for p in ps:
+            if p.dtype != F32 or not _dense(p) or p.device != dev:
+                raise N.NativeLibraryError('FusedSGD needs dense fp32 parameters on one device')
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4          # 16-byte aligned slots
+        old_bufs = self.bufs
+        self.flat_grad = torch.zeros(total, dtype=F32, device=dev)
+        self.flat_buf = torch.zeros(total, dtype=F32, device=dev)
+        self._views, self.bufs, rows = [], {}, []
+        for p, o in zip(ps, offs):
+            v = self.flat_grad[o:o + p.numel()].as_strided(p.shape, p.stride())
+            b = self.flat_buf[o:o + p.numel()].as_strided(p.shape, p.stride())
+            if id(p) in old_bufs and old_bufs[id(p)] is not None:
+                b.copy_(old_bufs[id(p)])
+            if not hasattr(p, '_mpr_hooked'):
+                p.register_post_accumulate_grad_hook(_mark_touched)
+                p._mpr_hooked = True
+            p._mpr_grad = v
+            if p.grad is None:
+                p.grad, p._mpr_touched = v, False
+            self._views.append(v)
+            self.bufs[id(p)] = b
+            rows.append([p.data_ptr(), v.data_ptr(), b.data_ptr(), p.numel()])
+        self._rows = rows
+        self._table_full = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self._max_numel = max(p.numel() for p in ps)
+        self._arena_key = key
 
     def zero_grad(self, set_to_none=True):
-        for p in self.params:
-            p.grad = None
-
-    def _build_table(self, live):
-        # pinned staging + device table are allocated once (also keeps the upload legal inside a HIP-graph
-        # capture, where allocating pinned memory is not)
-        if self._pinned is None:
-            self._pinned = torch.empty(len(self.params), 4, dtype=torch.int64).pin_memory()
-            self._table_dev = torch.empty(len(self.params), 4, dtype=torch.int64, device=live[0].device)
-        for i, p in enumerate(live):
-            if id(p) not in self.bufs:
-                self.bufs[id(p)] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            self._pinned[i, 0] = p.data_ptr()
-            self._pinned[i, 1] = p.grad.data_ptr()
-            self._pinned[i, 2] = self.bufs[id(p)].data_ptr()
-            self._pinned[i, 3] = p.numel()
-        self._table_dev[:len(live)].copy_(self._pinned[:len(live)], non_blocking=True)
-        return self._table_dev
+        """One memset of the flat gradient buffer; ``p.grad`` stays a (zero) view of it."""
+        if not self.params:
+            return
+        self._install()
+        self.flat_grad.zero_()
+        for p, v in zip(self.params, self._views):
+            if p.grad is not v:
+                p.grad = v
+            p._mpr_touched = False
 
     @torch.no_grad()
     def step(self):
-        live = [p for p in self.params if p.grad is not None]
+        if not self.params:
+            return
+        self._install()
+        live = []
+        for i, (p, v) in enumerate(zip(self.params, self._views)):
+            g = p.grad
+            if g is None:
+                continue
+            if g is not v:                      # assigned from outside: bring it into the flat buffer
+                v.copy_(g)
+                p.grad = v
+                live.append(i)
+            elif getattr(p, '_mpr_touched', False):
+                live.append(i)
         if not live:
             return
-        for p in live:
-            if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == F32 and p.grad.dtype == F32):
-                raise N.NativeLibraryError('FusedSGD needs contiguous fp32 parameters and gradients')
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
-        if key != self._table_key:
-            first_for = [id(p) not in self.bufs for p in live]
-            if any(first_for) and not all(first_for) and self.momentum:
-                # a parameter joined later: give it torch's "first step" (buf = g) by a solo launch below
-                raise N.NativeLibraryError('FusedSGD: parameter set changed after the first step')
-            self._table = self._build_table(live)
-            self._table_key = key
-        first = 1 if self.steps == 0 else 0
-        N.call('mpr_sgd_multi', self._table, len(live), max(p.numel() for p in live), self.lr, self.momentum,
-               self.dampening, self.weight_decay, int(self.nesterov), first)
+        new = [i for i in live if i not in self._seen]
+        if new and len(new) != len(live) and self.momentum:
+            # torch would give the newcomers a "first step" (buf = g) of their own
+            raise N.NativeLibraryError('FusedSGD: parameter set changed after the first step')
+        first = 1 if new else 0
+        if len(live) == len(self.params):
+            table = self._table_full
+            nmax = self._max_numel
+        else:
+            table = torch.tensor([self._rows[i] for i in live], dtype=torch.int64).to(self.flat_grad.device)
+            nmax = max(self._rows[i][3] for i in live)
+        N.call('mpr_sgd_multi', table, len(live), nmax, self.lr, self.momentum, self.dampening, self.weight_decay,
+               int(self.nesterov), first)
+        self._seen.update(live)
         self.steps += 1
-        # parameters were mutated through raw pointers: bump their version counters so that cached
-        # bf16 weight panels (packed_weights) are rebuilt
-        FusedSGD._bump_versions(live)
+        # parameters were mutated through raw pointers: bump their version counters, then refresh every cached
+        # bf16 filter panel in one launch (ops.packed_weights would otherwise repack filter by filter)
+        FusedSGD._bump_versions([self.params[i] for i in live])
+        pack_registry.repack_all()
 
     @staticmethod
     def _bump_versions(params):

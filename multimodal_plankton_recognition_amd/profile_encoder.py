@@ -11,7 +11,7 @@ from typing import Dict, Iterable
 import torch
 from torch import Tensor, nn
 
-from . import layers
+from . import layers, ops
 from .layers import BasicBlock, BatchNormParams, PoolTailFn, StemFn
 from .ops import ConvGeom
 
@@ -40,6 +40,7 @@ class ProfileCNN(nn.Module):
         self.p_drop = float(dropout)
         self.dim_out = base_channels * 8 + metadata
         self.metadata = metadata
+        ops.to_krsc_(self)              # block filters: [K][S][C] memory (state_dict / shapes unchanged)
 
     def _make_layer(self, repeat_times, channels, stride):
         layers_ = [BasicBlock(1, self.in_channels, channels, stride,
