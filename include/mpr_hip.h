@@ -50,7 +50,13 @@ int mpr_conv_pack_weights_strided(const float* w, long long sk, long long sc, lo
 /* every filter of a model in ONE launch (after the optimizer step): `table` = n device rows of 12 int64
  * {w, w_fwd, w_dgrad (0: none), K, C, R, S, sk, sc, sr, ss, 0} */
 int mpr_conv_pack_weights_multi(const void* table, int n, void* stream);
-int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S);
+int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S, int sh, int sw, int ph, int pw);
+/* 3x3 / stride 1 / pad 1 convolutions with source channels % 64 == 0 (forward and data gradient) run on the
+ * shifted-window kernel (conv_win.hip: the haloed activation window is loaded once per 64-channel block and all nine
+ * taps read it at shifted LDS rows); 0 switches it off (tests / comparisons); returns the previous setting */
+int mpr_conv_set_window(int on);
+/* tile / weight-ring variant of the shifted-window kernel (tuning knob, see conv_win.hip; default 4) */
+int mpr_conv_set_window_variant(int v);
 /* rows (B*P*Q) from which the LDS-DMA ring kernel replaces the register-staged one (default 16384);
  * returns the previous threshold */
 int mpr_conv_set_dma_min_rows(int rows);
@@ -59,6 +65,15 @@ int mpr_conv_set_variant(int narrow, int wide);
 /* stride-2 data gradient: regroup rows into the 4 (h mod 2, w mod 2) classes so a tile walks only the taps that
  * reach it (default 1 = on; 0 = issue every tap with zero-filled holes); returns the previous setting */
 int mpr_conv_set_dgrad_parity(int on);
+/* timing experiments only (results become wrong): bit 0 drops every load of the activation operand of the LDS-DMA
+ * conv kernel, bit 1 of the weight operand (zero-record buffer descriptors); returns the previous mask */
+int mpr_conv_debug_drop_operand(int mask);
+/* timing experiments only: the LDS-DMA conv kernel writes 4 time stamps (s_memrealtime, 100 MHz: start, prologue
+ * done, main loop done, end) per workgroup into buf[4 * workgroups] (uint64, device memory); NULL switches it off */
+int mpr_conv_debug_stamps(void* buf);
+/* timing experiments only: the shifted-window kernel writes, per workgroup, wave 0's shader-clock sums {total,
+ * waiting for DMA, waiting at the barrier, computing, epilogue, end time (100 MHz), -, -} into buf[8 * workgroups] */
+int mpr_conv_debug_probe(void* buf);
 /* output pixels (B*P*Q) from which the LDS-DMA weight-gradient kernel is used (default 16384) */
 int mpr_conv_set_wgrad_dma_min_pixels(int pixels);
 int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may be NULL */, int B, int H, int W,

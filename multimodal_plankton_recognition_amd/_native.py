@@ -113,8 +113,9 @@ def stream(device_index=None):
     return torch._C._cuda_getCurrentRawStream(device_index)
 
 
-def call(name, *args):
-    """Invoke an int-returning entry point on the current stream; tensors become device pointers."""
+def call(name, *args, stream_handle=None):
+    """Invoke an int-returning entry point on torch's current stream (or the given raw hipStream_t); tensors become
+    device pointers."""
     fn = getattr(lib(), name)
     conv = []
     dev = None
@@ -127,7 +128,7 @@ def call(name, *args):
                 dev = a.device.index
         else:
             conv.append(a)
-    rc = fn(*conv, stream(dev))
+    rc = fn(*conv, stream(dev) if stream_handle is None else stream_handle)
     if rc != 0:
         raise NativeLibraryError(f'{name} failed (rc={rc}): {last_error()}')
 

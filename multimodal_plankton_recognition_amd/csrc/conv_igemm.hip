@@ -31,6 +31,8 @@ struct ConvGemmParams {
   int R, S, sh, sw, ph, pw;
   FastDiv div_pq, div_q;   // row m -> (b, p, q)
   int Pm, Qm;
+  unsigned long long* stamps; // timing experiments: per-workgroup phase time stamps (100 MHz), or NULL
+  int dbg;                   // timing experiments: bit 2 / 3 = do not ISSUE the activation / weight DMA at all
   int par_rows, par_valid;   // stride-2 dgrad parity classes (LDS-DMA kernel): padded / real rows per class, 0 = off
 };
 
@@ -240,21 +242,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGemmParams p)
 // the fragment reads use the same XOR.  Padding taps / stride holes / the M tail are given an out-of-range
 // buffer offset: the descriptor's range check turns those lanes into zero writes.
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, and on gfx9 global STORES count
+// in vmcnt until acknowledged: an epilogue that syncs after its stores pays a full store round trip per barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int STAGES, bool DGRAD>
+// BK = K depth of a ring stage: 64 (128-B tile rows) or 32 (64-B rows: half the bytes per stage, so a deeper ring /
+// more workgroups per CU fit the 160 KB -- the loop is bound by the LATENCY of the operand stream, i.e. by the bytes
+// in flight per CU).  Swizzle keys: 128-B rows (row >> 1) & 7 over 8 chunks, 64-B rows (row >> 2) & 3
+// over 4 chunks; both make every ds_read_b128 lane group hit 16 distinct 16-B bank slots.
+template <int WM, int WN, int STAGES, bool DGRAD, int BK = 64>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const ConvGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass of hipcc
   constexpr int NW = WM * WN, T = 64 * NW;
   constexpr int BM = WM * 64, BN = WN * 64;
-  constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, IPC = A_IT + B_IT;
-  static_assert(A_IT % 2 == 0 && B_IT % 2 == 0, "instruction parity must follow the local index");
-  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int ROWB = BK * 2, CPRW = ROWB / 16, RPI = 64 / CPRW;   // row bytes, 16-B chunks per row, rows per DMA instr
+  constexpr int KS = BK / 16;                                       // MFMA k-steps per stage
+  constexpr int A_IT = BM / RPI / NW, B_IT = BN / RPI / NW, IPC = A_IT + B_IT;
+  static_assert(BK == 32 || (A_IT % 2 == 0 && B_IT % 2 == 0), "instruction parity must follow the local index");
+  static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the DMA instruction shape");
+  constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;
   constexpr int CS_STRIDE = BN * 4 + 16;
-  // (the host sizes the dynamic LDS as max(ring, epilogue tile))
+  // (the host sizes the dynamic LDS as max(ring, one 64-row slab of the epilogue tile))
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -263,13 +280,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = bid / p.ntn, nt = bid - mt * p.ntn;
   const int m0 = mt * BM, n0 = nt * BN;
+#define MPR_STAMP(k) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+  MPR_STAMP(0);
 
   // DMA geometry: instruction I covers tile rows 8I..8I+7; lane -> (row 8I + lane/8, physical chunk lane%8)
   // Source addressing is linear in the tap: byte offset = row part (VGPR, fixed) + tap part (SGPR, per chunk);
   // validity of each of the <= 32 taps for a row is one bit of a per-row mask, and invalid lanes get an
   // out-of-range buffer offset, for which the hardware range check makes the DMA write zeros.
-  const int lrow = lane >> 3;
-  const int lc_even = (lane & 7) ^ (lane >> 4);        // logical chunk for even I; odd I: ^ 4
+  //   BK = 32: instruction I covers rows 16I..16I+15; lane -> (row 16I + lane/4, physical chunk lane%4), key lane>>4
+  const int lrow = BK == 64 ? lane >> 3 : lane >> 2;
+  const int lc_even = BK == 64 ? (lane & 7) ^ (lane >> 4)         // logical chunk for even I; odd I: ^ 4
+                               : (lane & 3) ^ (lane >> 4);        // (no instruction parity with 64-B rows)
+  constexpr int PARITY_XOR = BK == 64 ? 4 : 0;
   //   fwd  : pix = rbase + (rh + r)*sW + (rw + s)                      -> ch =  2*sC*sW,      cw =  2*sC
   //   dgrad: pix = rbase + ((rh - r)/sh)*sW + (rw - s)/sw  (when valid) -> ch = -2*sC*sW/sh,  cw = -2*sC/sw
   const int tstep_h = DGRAD ? -(2 * p.sC * p.sW) / p.sh : 2 * p.sC * p.sW;
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   uint32_t voff[A_IT], vmask[A_IT];
 #pragma unroll
   for (int j = 0; j < A_IT; ++j) {
-    const int m = m0 + 8 * (wid * A_IT + j) + lrow - mbase;
+    const int m = m0 + RPI * (wid * A_IT + j) + lrow - mbase;
     voff[j] = 0;
     vmask[j] = 0;
     if (m < (PAR ? p.par_valid : p.M)) {
@@ -298,7 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
       int rh, rw;
       if (!DGRAD) { rh = (int)pp * p.sh - p.ph; rw = (int)qq * p.sw - p.pw; }
       else        { rh = (int)pp + p.ph;        rw = (int)qq + p.pw; }
-      const int lc = lc_even ^ ((j & 1) << 2);
+      const int lc = lc_even ^ ((j & 1) ? PARITY_XOR : 0);
       voff[j] = (uint32_t)(b * p.sH * p.sW) * (uint32_t)(2 * p.sC) + (uint32_t)(rh * (DGRAD ? -tstep_h : tstep_h)) +
                 (uint32_t)(rw * (DGRAD ? -tstep_w : tstep_w)) + (uint32_t)(lc * 16);
       // tap (r, s) is valid iff row-tap r and column-tap s are both valid (the conditions are per axis):
@@ -343,35 +365,38 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   uint32_t boff[B_IT];
 #pragma unroll
   for (int j = 0; j < B_IT; ++j)
-    boff[j] = ((uint32_t)(n0 + 8 * (wid * B_IT + j) + lrow) * (uint32_t)p.Kgpad + (lc_even ^ ((j & 1) << 2)) * 8) * 2;
+    boff[j] = ((uint32_t)(n0 + RPI * (wid * B_IT + j) + lrow) * (uint32_t)p.Kgpad +
+               (lc_even ^ ((j & 1) ? PARITY_XOR : 0)) * 8) * 2;
   const __amdgpu_buffer_rsrc_t rs_a =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, p.wpk_bytes, 0x00020000);
 
-  const int ncb = p.sC >> 6;     // 64-channel blocks per tap
+  const int ncb = p.sC / BK;     // BK-channel blocks per tap
   const int ntaps = p.R * p.S;
   // parity classes walk only the taps r = tr0, tr0+2, ... / s = ts0, ts0+2, ... of their class
   const int tr0 = PAR ? ((par_h + p.ph) & 1) : 0, ts0 = PAR ? ((par_w + p.pw) & 1) : 0;
   const int tstep = PAR ? 2 : 1;
-  const int nk = PAR ? ((p.R - tr0 + 1) >> 1) * ((p.S - ts0 + 1) >> 1) * ncb : p.nk;
+  const int nk = PAR ? ((p.R - tr0 + 1) >> 1) * ((p.S - ts0 + 1) >> 1) * ncb : p.nk * (64 / BK);
   int tr = tr0, ts = ts0, cb = 0, tap = tr0 * p.S + ts0;    // wave-uniform tap state of the NEXT chunk to issue
   auto issue_chunk = [&](int kc, int buf) {
     unsigned char* sa = smem + buf * STAGE;
     unsigned char* sb = sa + A_BYTES;
-    const uint32_t toff = (uint32_t)(tr * tstep_h + ts * tstep_w + cb * 128);
+    const uint32_t toff = (uint32_t)(tr * tstep_h + ts * tstep_w + cb * ROWB);
     const uint32_t bit = tap < ntaps ? (1u << tap) : 0u;      // K padding chunks: every lane reads zeros
     if (PAR) kc = tap * ncb + cb;                             // weight chunk of this (tap, channel block)
+    if (!(p.dbg & 4))
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
       const uint32_t v = (vmask[j] & bit) ? voff[j] + toff : 0xFFFFFFF0u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(sa + (wid * A_IT + j) * 1024),
                                                16, v, 0, 0, 0);
     }
+    if (!(p.dbg & 8))
 #pragma unroll
     for (int j = 0; j < B_IT; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(sb + (wid * B_IT + j) * 1024),
-                                               16, boff[j], kc * 128, 0, 0);
+                                               16, boff[j], kc * ROWB, 0, 0);
     if (++cb == ncb) {
       cb = 0;
       ts += tstep;
@@ -391,15 +416,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   int issued = 0;
   for (; issued < STAGES - 1 && issued < nk; ++issued) issue_chunk(issued, issued % STAGES);
 
+  MPR_STAMP(1);
   const int frow = lane & 31, fh = lane >> 5;
   // fragment read offsets inside a stage: row*128 + (((2*ks + fh) ^ key) << 4), key = (row >> 1) & 7 = (frow >> 1) & 7
-  uint32_t a_rd[2][4], b_rd[2][4];
+  //                                     (64-B rows: row*64 + (((2*ks + fh) ^ ((row >> 2) & 3)) << 4))
+  auto frag_off = [](int row, int chunk) {
+    return BK == 64 ? swz_off(row, chunk) : row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+  };
+  uint32_t a_rd[2][KS], b_rd[2][KS];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      a_rd[t][ks] = swz_off(wm * 64 + t * 32 + frow, ks * 2 + fh);
-      b_rd[t][ks] = A_BYTES + swz_off(wn * 64 + t * 32 + frow, ks * 2 + fh);
+    for (int ks = 0; ks < KS; ++ks) {
+      a_rd[t][ks] = frag_off(wm * 64 + t * 32 + frow, ks * 2 + fh);
+      b_rd[t][ks] = A_BYTES + frag_off(wn * 64 + t * 32 + frow, ks * 2 + fh);
     }
   for (int kc = 0; kc < nk; ++kc) {
     // retire chunk kc: everything but the (issued - kc - 1) younger chunks of THIS wave must have landed
@@ -409,77 +439,107 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (issued < nk) { issue_chunk(issued, issued % STAGES); ++issued; }
     const unsigned char* a = smem + (kc % STAGES) * STAGE;
+    // software-pipelined k-steps: the fragments of step ks+1 are in flight (their own registers) while the four
+    // MFMAs of step ks run -- left to itself hipcc reuses one register set and exposes the LDS latency 4x per chunk.
+    // The first reads go out BEFORE the next chunk's DMA is issued, so its address arithmetic hides their latency.
+    bf16x8 af[2][2], bfr[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 af[2], bfr[2];
+    for (int t = 0; t < 2; ++t) {
+      af[0][t] = *reinterpret_cast<const bf16x8*>(a + a_rd[t][0]);
+      bfr[0][t] = *reinterpret_cast<const bf16x8*>(a + b_rd[t][0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (issued < nk) { issue_chunk(issued, issued % STAGES); ++issued; }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        af[t] = *reinterpret_cast<const bf16x8*>(a + a_rd[t][ks]);
-        bfr[t] = *reinterpret_cast<const bf16x8*>(a + b_rd[t][ks]);
+    for (int ks = 0; ks < KS; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < KS - 1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          af[nxt][t] = *reinterpret_cast<const bf16x8*>(a + a_rd[t][ks + 1]);
+          bfr[nxt][t] = *reinterpret_cast<const bf16x8*>(a + b_rd[t][ks + 1]);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[i], af[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][i], af[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();
 
-  // ---- epilogue (as the register-staged kernel): fp32 tile -> LDS -> 16-B channel groups
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = wm * 64 + j * 32 + frow;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = wn * 64 + i * 32 + 8 * g + 4 * fh;
-        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
-      }
-    }
-  __syncthreads();
-
+  // Every DMA has landed (the loop's own waits are inline asm the compiler cannot see): say so with a wait it CAN see,
+  // or it guards each LDS access of the epilogue with vmcnt(0) -- which, once the first global stores are out, waits
+  // for their acknowledgement (a store round trip per slab).
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+  MPR_STAMP(2);
+  // ---- epilogue: one 64-row slab of the fp32 tile at a time -> LDS -> 16-B channel groups (+ residual, BN partial sums).
+  // Slab by slab keeps the LDS need at 64 rows (34 KB at BN = 128), below the ring, so the ring alone sets occupancy.
   constexpr int CPR = BN / 8;
   constexpr int RPP = T / CPR;
+  static_assert(64 % RPP == 0, "a slab must be whole row passes");
   const int ch = tid % CPR, rr = tid / CPR;
   const int ncol = n0 + ch * 8;
   const bool col_ok = ncol < p.Nout;
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-#pragma unroll 4
-  for (int r = rr; r < BM; r += RPP) {
-    int m = m0 + r - mbase;
-    bool row_ok = m < (PAR ? p.par_valid : p.M);
-    if (PAR && row_ok) {     // class-local row -> pixel (b, 2*h2 + par_h, 2*w2 + par_w) of the [B, 2*Pm, 2*Qm] gradient
-      const uint32_t b = fdiv(m, p.div_pq);
-      const uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
-      const uint32_t h2 = fdiv(rem, p.div_q);
-      const uint32_t w2 = rem - h2 * p.Qm;
-      m = ((b * 2 * p.Pm + 2 * h2 + par_h) * 2 * p.Qm) + 2 * w2 + par_w;
+  if (p.dbg & 16) {      // timing experiment: no epilogue (one store keeps the accumulators alive)
+    if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) p.dst[0] = (bf16_t)1.f;
+    return;
+  }
+#pragma unroll 1
+  for (int slab = 0; slab < WM; ++slab) {
+    lds_barrier();      // ring (first pass) / previous slab fully consumed
+    if (wm == slab) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = j * 32 + frow;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = wn * 64 + i * 32 + 8 * g + 4 * fh;
+            float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
+          }
+        }
     }
-    if (row_ok && col_ok) {
-      const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
-      const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
-      float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      const size_t o = (size_t)m * p.Nout + ncol;
-      if (p.add) {
-        float g[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.add + o), g);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += g[e];
+    lds_barrier();
+#pragma unroll 2
+    for (int r = rr; r < 64; r += RPP) {
+      int m = m0 + slab * 64 + r - mbase;
+      bool row_ok = m < (PAR ? p.par_valid : p.M);
+      if (PAR && row_ok) {     // class-local row -> pixel (b, 2*h2 + par_h, 2*w2 + par_w) of the [B, 2*Pm, 2*Qm] gradient
+        const uint32_t b = fdiv(m, p.div_pq);
+        const uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
+        const uint32_t h2 = fdiv(rem, p.div_q);
+        const uint32_t w2 = rem - h2 * p.Qm;
+        m = ((b * 2 * p.Pm + 2 * h2 + par_h) * 2 * p.Qm) + 2 * w2 + par_w;
       }
-      const uint4 pk = pack8(f);
-      *reinterpret_cast<uint4*>(p.dst + o) = pk;
-      if (p.stats) {
-        float q[8];
-        unpack8(pk, q);
+      if (row_ok && col_ok) {
+        const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
+        const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
+        float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const size_t o = (size_t)m * p.Nout + ncol;
+        if (p.add) {
+          float g[8];
+          unpack8(*reinterpret_cast<const uint4*>(p.add + o), g);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+          for (int e = 0; e < 8; ++e) f[e] += g[e];
+        }
+        const uint4 pk = pack8(f);
+        *reinterpret_cast<uint4*>(p.dst + o) = pk;
+        if (p.stats) {
+          float q[8];
+          unpack8(pk, q);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+        }
       }
     }
   }
@@ -491,7 +551,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         s1[e] += __shfl_xor(s1[e], o, 64);
         s2[e] += __shfl_xor(s2[e], o, 64);
       }
-    __syncthreads();
+    lds_barrier();
     float* red = reinterpret_cast<float*>(smem);   // [NW waves][CPR][16]
     if (lane < CPR) {
 #pragma unroll
@@ -500,7 +560,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         red[(wid * CPR + lane) * 16 + 8 + e] = s2[e];
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < CPR * 16) {
       const int c = tid >> 4, e = tid & 15;
       float v = 0.f;
@@ -510,6 +570,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
       if (n < p.Nout) p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
     }
   }
+  MPR_STAMP(3);
+#undef MPR_STAMP
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
@@ -602,6 +664,13 @@ int mpr_conv_pack_weights_multi(const void* table, int n, void* stream) {
 // Kernel / tile selection, shared by the launcher and the stat-row query.
 //   mode 1: LDS-DMA ring  (source channels % 64 == 0 and enough rows to fill the chip)
 //   mode 0: register-staged kernel (any channel count that is a multiple of 8; small problems)
+// shifted-window kernel for 3x3 / stride 1 / pad 1 (conv_win.hip)
+bool mpr_win_eligible(long long M, int H, int W, int srcC, int Nout, int R, int S, int sh, int sw, int ph, int pw,
+                      long long min_rows);
+int mpr_win_tiles(int B, int H, int W);
+int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, const void* add, float* stats, int B, int H,
+                   int W, int srcC, int Nout, hipStream_t st);
+
 static int g_dma_min_rows = 16384;
 extern "C" int mpr_conv_set_dma_min_rows(int rows) {   // tuning / test knob; returns the previous value
   const int old = g_dma_min_rows;
@@ -611,7 +680,10 @@ extern "C" int mpr_conv_set_dma_min_rows(int rows) {   // tuning / test knob; re
 
 // tile / ring-depth variants of the LDS-DMA kernel (tuning knob; defaults are the measured best)
 //   narrow (N <= 64): 0 = 256x64, 2 stages (2 WG/CU)   1 = 256x64, 3 stages (1 WG/CU)   2 = 128x64, 2 stages (3 WG/CU)
+//                     3 = 256x64, BK 32, 4 stages        4 = 256x64, BK 32, 3 stages
 //   wide   (N > 64) : 0 = 256x128, 3 stages, 8 waves    1 = 128x128, 2 stages (2 WG/CU)   2 = 128x128, 3 stages
+//                     3 = 128x128, BK 32, 3 stages (3 WG/CU)   4 = 128x128, BK 32, 4 stages (2 WG/CU)
+//                     5 = 256x128, BK 32, 3 stages (2 WG/CU)   6 = 256x128, BK 32, 4 stages (1 WG/CU)
 static int g_variant_narrow = 0, g_variant_wide = 1;
 extern "C" int mpr_conv_set_variant(int narrow, int wide) {
   g_variant_narrow = narrow;
@@ -619,6 +691,17 @@ extern "C" int mpr_conv_set_variant(int narrow, int wide) {
   return 0;
 }
 
+static unsigned long long* g_debug_stamps = nullptr;
+extern "C" int mpr_conv_debug_stamps(void* buf) {   // 4 x uint64 per workgroup of the next LDS-DMA conv launches
+  g_debug_stamps = (unsigned long long*)buf;
+  return 0;
+}
+static int g_debug_drop = 0;   // bit 0: drop the activation operand's loads, bit 1: the weight operand's (LDS-DMA kernel)
+extern "C" int mpr_conv_debug_drop_operand(int mask) {
+  const int old = g_debug_drop;
+  g_debug_drop = mask;
+  return old;
+}
 static int g_dgrad_parity = 1;
 extern "C" int mpr_conv_set_dgrad_parity(int on) {
   const int old = g_dgrad_parity;
@@ -630,7 +713,8 @@ static inline void igemm_config(long long M, int Nout, int srcC, int taps, int* 
   const bool narrow = Nout <= 64;
   if (srcC % 64 == 0 && taps <= 32 && M >= g_dma_min_rows) {
     *mode = 1; *BN = narrow ? 64 : 128;
-    *BM = narrow ? (g_variant_narrow == 2 ? 128 : 256) : (g_variant_wide != 0 ? 128 : 256);
+    *BM = narrow ? (g_variant_narrow == 2 ? 128 : 256)
+                 : ((g_variant_wide == 0 || g_variant_wide == 5 || g_variant_wide == 6) ? 256 : 128);
   } else {
     *mode = 0; *BM = narrow ? 256 : 128; *BN = narrow ? 64 : 128;
   }
@@ -666,33 +750,51 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   const int gm = ceil_div(p.M, BM);
   dim3 grid(gm * p.ntn);
   // profiler kinds: 0/1 = LDS-DMA kernel fwd/dgrad (the dominant kernel), 3/4 = register-staged kernel fwd/dgrad
+  // timing-only experiment (MI355X guide, traffic pricing): a zero-record descriptor drops every load through it
+  p.dbg = g_debug_drop;
+  p.stamps = g_debug_stamps;
+  if (g_debug_drop & 1) p.src_bytes = 0;
+  if (g_debug_drop & 2) p.wpk_bytes = 0;
   void* tok = mpr_prof_begin((mode == 1 ? 0 : 3) + (dgrad ? 1 : 0), flops, st);
   mpr_prof_bytes(tok, algo_bytes);
   if (mode == 1) {
-#define MPR_DMA(WM_, WN_, ST_, DG_)                                                                   \
+#define MPR_DMA5(WM_, WN_, ST_, DG_, BK_)                                                                 \
   do {                                                                                                \
     static bool attr_set = false;                                                                     \
     if (!attr_set) {                                                                                  \
-      hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<WM_, WN_, ST_, DG_>,                     \
+      hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<WM_, WN_, ST_, DG_, BK_>,                \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_set = true;                                                                                \
     }                                                                                                 \
-    const size_t ring_ = (size_t)ST_ * (64 * WM_ + 64 * WN_) * 128;                                   \
-    const size_t epi_ = (size_t)(64 * WM_) * (64 * WN_ * 4 + 16);                                     \
-    conv_igemm_dma_kernel<WM_, WN_, ST_, DG_>                                                         \
+    const size_t ring_ = (size_t)ST_ * (64 * WM_ + 64 * WN_) * (2 * BK_);                             \
+    const size_t epi_ = (size_t)64 * (64 * WN_ * 4 + 16);                                             \
+    conv_igemm_dma_kernel<WM_, WN_, ST_, DG_, BK_>                                                    \
         <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                               \
   } while (0)
+#define MPR_DMA(WM_, WN_, ST_, BK_) do { if (dgrad) MPR_DMA5(WM_, WN_, ST_, true, BK_); else MPR_DMA5(WM_, WN_, ST_, false, BK_); } while (0)
     if (narrow) {
-      if (g_variant_narrow == 1)      { if (dgrad) MPR_DMA(4, 1, 3, true); else MPR_DMA(4, 1, 3, false); }
-      else if (g_variant_narrow == 2) { if (dgrad) MPR_DMA(2, 1, 2, true); else MPR_DMA(2, 1, 2, false); }
-      else                            { if (dgrad) MPR_DMA(4, 1, 2, true); else MPR_DMA(4, 1, 2, false); }
+      switch (g_variant_narrow) {
+        case 1: MPR_DMA(4, 1, 3, 64); break;
+        case 2: MPR_DMA(2, 1, 2, 64); break;
+        case 3: MPR_DMA(4, 1, 4, 32); break;
+        case 4: MPR_DMA(4, 1, 3, 32); break;
+        default: MPR_DMA(4, 1, 2, 64); break;
+      }
+    } else if (s2dgrad) {
+      MPR_DMA5(4, 2, 3, true, 64);
     } else {
-      if (s2dgrad)                  { MPR_DMA(4, 2, 3, true); }
-      else if (g_variant_wide == 1) { if (dgrad) MPR_DMA(2, 2, 2, true); else MPR_DMA(2, 2, 2, false); }
-      else if (g_variant_wide == 2) { if (dgrad) MPR_DMA(2, 2, 3, true); else MPR_DMA(2, 2, 3, false); }
-      else                          { if (dgrad) MPR_DMA(4, 2, 3, true); else MPR_DMA(4, 2, 3, false); }
+      switch (g_variant_wide) {
+        case 0: MPR_DMA(4, 2, 3, 64); break;
+        case 2: MPR_DMA(2, 2, 3, 64); break;
+        case 3: MPR_DMA(2, 2, 3, 32); break;
+        case 4: MPR_DMA(2, 2, 4, 32); break;
+        case 5: MPR_DMA(4, 2, 3, 32); break;
+        case 6: MPR_DMA(4, 2, 4, 32); break;
+        default: MPR_DMA(2, 2, 2, 64); break;
+      }
     }
 #undef MPR_DMA
+#undef MPR_DMA5
   } else {
     const size_t stage2 = (size_t)2 * (BM + BN) * 128, epi = (size_t)BM * (BN * 4 + 16);
     const size_t smem = stage2 > epi ? stage2 : epi;
@@ -716,7 +818,9 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
 }
 
 // Number of row tiles (= rows of the BatchNorm partial-sum buffer) mpr_conv_fwd will use.
-int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S) {
+int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S, int sh, int sw, int ph, int pw) {
+  if (mpr_win_eligible((long long)B * P * Q, P, Q, C, K, R, S, sh, sw, ph, pw, g_dma_min_rows))   // (stride 1: H == P)
+    return mpr_win_tiles(B, P, Q);
   int mode, BM, BN;
   igemm_config((long long)B * P * Q, K, C, R * S, &mode, &BM, &BN);
   return ceil_div(B * P * Q, BM);
@@ -732,6 +836,14 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
   MPR_REQUIRE(P > 0 && Q > 0, "mpr_conv_fwd: empty output");
   MPR_REQUIRE((long long)B * H * W * C < (1ll << 31) && (long long)B * P * Q * K < (1ll << 31),
               "mpr_conv_fwd: tensor exceeds 2^31 elements");
+  if (mpr_win_eligible((long long)B * P * Q, H, W, C, K, R, S, sh, sw, ph, pw, g_dma_min_rows)) {
+    // 3x3 / stride 1 / pad 1: shifted-window kernel (conv_win.hip)
+    void* tok = mpr_prof_begin(0, 2.0 * (double)B * P * Q * K * 9.0 * C, (hipStream_t)stream);
+    mpr_prof_bytes(tok, 2.0 * ((double)B * H * W * C + 9.0 * C * K + (double)B * P * Q * K));
+    const int rc = mpr_win_launch(false, x, w_fwd, y, nullptr, stats, B, H, W, C, K, (hipStream_t)stream);
+    mpr_prof_end(tok, (hipStream_t)stream);
+    return rc;
+  }
   ConvGemmParams p;
   p.src = (const bf16_t*)x; p.wpk = (const bf16_t*)w_fwd; p.dst = (bf16_t*)y; p.add = nullptr; p.stats = stats;
   p.sH = H; p.sW = W; p.sC = C;
@@ -753,6 +865,13 @@ int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* ad
   MPR_REQUIRE(P > 0 && Q > 0, "mpr_conv_dgrad: empty output");
   MPR_REQUIRE((long long)B * H * W * C < (1ll << 31) && (long long)B * P * Q * K < (1ll << 31),
               "mpr_conv_dgrad: tensor exceeds 2^31 elements");
+  if (mpr_win_eligible((long long)B * H * W, H, W, K, C, R, S, sh, sw, ph, pw, g_dma_min_rows)) {
+    void* tok = mpr_prof_begin(1, 2.0 * (double)B * H * W * C * 9.0 * K, (hipStream_t)stream);
+    mpr_prof_bytes(tok, 2.0 * ((double)B * P * Q * K + 9.0 * C * K + (double)B * H * W * C * (add ? 2 : 1)));
+    const int rc = mpr_win_launch(true, dy, w_dgrad, dx, add, nullptr, B, H, W, K, C, (hipStream_t)stream);
+    mpr_prof_end(tok, (hipStream_t)stream);
+    return rc;
+  }
   ConvGemmParams p;
   p.src = (const bf16_t*)dy; p.wpk = (const bf16_t*)w_dgrad; p.dst = (bf16_t*)dx; p.add = (const bf16_t*)add;
   p.stats = nullptr;

@@ -1,0 +1,468 @@
+// Shifted-window implicit GEMM for 3x3 / stride 1 / pad 1 convolutions (forward and data gradient) -- the 13 "body"
+// convolutions of a ResNet-18 (timm BasicBlock conv1/conv2 behind src/image_encoder.py:24), which carry 80 % of its
+// FLOPs.
+//
+// Why a second kernel: measured per-workgroup phase times (scripts/conv_phases.py) put the plain LDS-DMA implicit
+// GEMM (conv_igemm.hip) exactly on the CU's global->LDS fill rate (~73 GB/s per CU, MI355X guide "gather into LDS"):
+// it re-fetches every input pixel once per filter tap, 32 KB of operands per 2.1 MFLOP chunk.  Here the activation
+// operand of a 256-row tile is loaded ONCE per 64-channel block as a haloed window and all nine taps read it at
+// shifted LDS rows; only the weight panel still streams per (tap, channel block).  That is 185 KB per 37.7 MFLOP
+// (204 FLOP/B instead of 64), which moves the loop from the fill rate to the MFMA pipe.
+//
+// The shift must be LINEAR in the LDS row for that, so pixels are numbered in a padded raster: one zero column after
+// every image row and one zero row after every image (G = (b*(H+1) + h)*(W+1) + w).  Tap (r, s) of output G then
+// reads position G + (r-1)*(W+1) + (s-1) (data gradient: the mirrored shift), and every out-of-image neighbour IS a
+// pad position -- which the window DMA zero-fills through an out-of-range buffer offset.  An output tile is 256
+// consecutive padded positions (3.6 % .. 31 % of them pads, dropped in the epilogue); its window is the tile plus
+// W+2 rows of halo on both sides.
+//
+// Workgroup = 4 waves.  Wide tile 256 x 128: waves 2 x 2, each 128 x 64 as 4 x 2 v_mfma_f32_32x32x16_bf16 (a weight
+// fragment feeds four MFMAs, an activation fragment two); narrow tile 256 x 64 (64 output channels): waves 4 x 1,
+// each 64 x 64.  LDS: window (<= 47 KB) + 2-stage weight ring (2 x 16 KB) -> two workgroups per CU.
+#include "common.h"
+
+struct WinParams {
+  const bf16_t* src;   // [B,H,W,C] (forward: x; data gradient: dy)
+  const bf16_t* wpk;   // packed panel [Npad128][9*C]
+  bf16_t* dst;         // [B,H,W,Nout]
+  const bf16_t* add;   // optional residual [B,H,W,Nout]
+  float* stats;        // optional [tiles_m][2][Nout]
+  int H, W, C, Nout;
+  int Wp, img, halo, Gtot, wrows;   // W+1, (H+1)*(W+1), W+2, B*img, 256 + 2*halo
+  int ntn, Kgpad, ncb;
+  unsigned src_bytes, wpk_bytes;
+  FastDiv div_img, div_wp;
+  unsigned long long* probe;   // timing experiments: 8 x uint64 of shader-clock sums per workgroup, or NULL
+};
+
+__device__ __forceinline__ int win_swz(int row, int chunk) {   // byte offset in a [rows][128 B] image
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__device__ __forceinline__ void win_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_win() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WM, int WN, int TM, int TN, int STAGES, bool DGRAD>
+__global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WM * WN, T = 64 * NW;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static_assert(BM == 256 && TM % 2 == 0, "tile height is fixed at 256 rows");
+  constexpr int WI_MAX = (BM + 2 * 58 + 7) / 8;        // window DMA instructions at the largest halo (W = 56)
+  constexpr int WIW = (WI_MAX + NW - 1) / NW;          // ... per wave
+  constexpr int B_IT = BN / 8 / NW;
+  static_assert(B_IT >= 1, "weight tile too small for the DMA instruction shape");
+  constexpr int BSTAGE = BN * 128;
+  constexpr int CS_STRIDE = BN * 4 + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / p.ntn, nt = bid - mt * p.ntn;
+  const int G0 = mt * BM, n0 = nt * BN;
+  const int wrows8 = (p.wrows + 7) & ~7;
+  unsigned char* const bring = smem + wrows8 * 128;
+
+  // ---- window DMA geometry: instruction I covers window rows 8I..8I+7, lane -> (row 8I + lane/8, physical chunk lane%8);
+  //      the bank swizzle (logical chunk = physical ^ ((row >> 1) & 7)) is applied on the SOURCE side
+  uint32_t wvoff[WIW];
+  uint32_t wmask = 0;
+#pragma unroll
+  for (int k = 0; k < WIW; ++k) {
+    const int I = wid + k * NW;
+    const int j = 8 * I + (lane >> 3);
+    const int G = G0 - p.halo + j;
+    wvoff[k] = 0;
+    if (j < p.wrows && G >= 0 && G < p.Gtot) {
+      const uint32_t b = fdiv(G, p.div_img);
+      const uint32_t pp = G - b * p.img;
+      const uint32_t hh = fdiv(pp, p.div_wp);
+      const uint32_t ww = pp - hh * p.Wp;
+      if (hh < (uint32_t)p.H && ww < (uint32_t)p.W) {
+        const uint32_t pix = (b * p.H + hh) * p.W + ww;
+        const int lc = (lane & 7) ^ ((4 * I + (lane >> 4)) & 7);
+        wvoff[k] = pix * (uint32_t)(2 * p.C) + lc * 16;
+        wmask |= 1u << k;
+      }
+    }
+  }
+  uint32_t boff[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int q = wid * B_IT + j;
+    const int lc = (lane & 7) ^ ((4 * q + (lane >> 4)) & 7);
+    boff[j] = ((uint32_t)(n0 + 8 * q + (lane >> 3)) * (uint32_t)p.Kgpad + lc * 8) * 2;
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, p.wpk_bytes, 0x00020000);
+
+  auto issue_window = [&](int cb) {
+#pragma unroll
+    for (int k = 0; k < WIW; ++k) {
+      const int I = wid + k * NW;
+      if (8 * I < wrows8) {     // wave-uniform
+        const uint32_t v = ((wmask >> k) & 1u) ? wvoff[k] + cb * 128 : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(smem + I * 1024), 16, v,
+                                                 0, 0, 0);
+      }
+    }
+  };
+  auto issue_weights = [&](int tap, int cb, int stage) {
+    const int soff = (tap * p.ncb + cb) * 128;
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_b, (__attribute__((address_space(3))) void*)(bring + stage * BSTAGE + (wid * B_IT + j) * 1024), 16, boff[j],
+          soff, 0, 0);
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+
+  const int frow = lane & 31, fh = lane >> 5;
+  const int baseA = wm * (TM * 32) + frow + p.halo;       // window row of this lane's pixel, m-tile 0, no shift
+  uint32_t b_rd[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b_rd[j][ks] = win_swz(wn * (TN * 32) + j * 32 + frow, ks * 2 + fh);
+
+  // (timing probe: wave 0's shader-clock sums of the loop phases; all dead code when p.probe == NULL)
+  unsigned long long pr_t0 = 0, pr_wait = 0, pr_bar = 0, pr_comp = 0, pr_a = 0, pr_b = 0, pr_loop = 0, pr_rbar = 0,
+                     pr_riss = 0, pr_ew = 0, pr_er = 0;
+#define PROBE_NOW() (p.probe ? __builtin_readcyclecounter() : 0ull)
+  pr_t0 = PROBE_NOW();
+  issue_window(0);
+  const int nk = 9 * p.ncb;
+  // weight ring: chunk kc lives in stage kc % STAGES and is issued STAGES-1 chunks ahead (the loop is bound by the
+  // LATENCY of that stream: one chunk of look-ahead leaves every iteration waiting for its own weights)
+  int itap = 0, icb = 0, issued = 0;          // (tap, channel block) of the next chunk to issue
+  auto issue_next = [&]() {
+    issue_weights(itap, icb, issued % STAGES);
+    ++issued;
+    if (++itap == 9) { itap = 0; ++icb; }
+  };
+  for (int i = 0; i < STAGES - 1 && i < nk; ++i) issue_next();
+  int tap = 0, cb = 0, tr = 0, ts = 0;
+  for (int kc = 0; kc < nk; ++kc) {
+    bool drain = kc == 0;
+    if (tap == 0 && cb > 0) {
+      // next 64-channel block: every wave is done with the old window (it sits behind this barrier), reload it
+      const unsigned long long q0 = PROBE_NOW();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned long long q1 = PROBE_NOW();
+      issue_window(cb);
+      pr_rbar += q1 - q0;
+      pr_riss += PROBE_NOW() - q1;
+      drain = true;
+    }
+    // retire chunk kc: at most the (issued - kc - 1) younger weight chunks of THIS wave may still be in flight
+    const int younger = issued - kc - 1;
+    pr_a = PROBE_NOW();
+    if (!drain && STAGES >= 3 && younger == STAGES - 2) wait_vmcnt_win<(STAGES - 2) * B_IT>();
+    else wait_vmcnt_win<0>();
+    pr_b = PROBE_NOW();
+    pr_wait += pr_b - pr_a;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    pr_a = PROBE_NOW();
+    pr_bar += pr_a - pr_b;
+
+    // shifted fragment rows of this tap: rows of the TM m-tiles are 32 apart -> same swizzle key, immediate offsets
+    const int d = DGRAD ? (1 - tr) * p.Wp + (1 - ts) : (tr - 1) * p.Wp + (ts - 1);
+    const int rowA = baseA + d;
+    const int key = (rowA >> 1) & 7;
+    const unsigned char* const arow = smem + rowA * 128;
+    const unsigned char* const bst = bring + (kc % STAGES) * BSTAGE;
+    bf16x8 af[2][TM], bfr[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(arow + i * 4096 + ((fh ^ key) << 4));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(bst + b_rd[j][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (issued < nk) issue_next();     // (into the stage chunk kc-1 just vacated) behind the first fragment reads
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[nxt][i] = *reinterpret_cast<const bf16x8*>(arow + i * 4096 + (((2 * (ks + 1) + fh) ^ key) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(bst + b_rd[j][ks + 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[j][i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++ts == 3) { ts = 0; ++tr; }
+    if (++tap == 9) { tap = 0; tr = 0; ++cb; }
+    pr_comp += PROBE_NOW() - pr_a;
+  }
+  pr_loop = PROBE_NOW();
+  // every DMA has landed; say so with a wait the compiler can see (see conv_igemm.hip)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  // ---- epilogue: 64-row slabs of the fp32 tile -> LDS -> 16-B channel groups (+ residual, BN partial sums); pad
+  //      positions of the raster are dropped here
+  constexpr int CPR = BN / 8;
+  constexpr int RPP = T / CPR;
+  static_assert(64 % RPP == 0, "a slab must be whole row passes");
+  const int ch = tid % CPR, rr = tid / CPR;
+  const int ncol = n0 + ch * 8;
+  const bool col_ok = ncol < p.Nout;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (!p.add) {
+    // No residual: the tile is rounded to bf16 IN REGISTERS and staged as bf16 (half the LDS bytes), every wave writing
+    // its own rows at once -- one pass of 256 rows at BN = 64, two of 128 rows at BN = 128 (LDS capacity) -- and the
+    // read side hands finished 16-B channel groups to the global store.  (The slab path below serialises the waves and
+    // moves fp32; it is kept for the fused residual add, which must see the unrounded accumulator.)
+    constexpr int EP = BN == 64 ? 1 : 2;          // passes
+    constexpr int RPASS = BM / EP;                // rows per pass
+    constexpr int RS = BN * 2 + 16;               // staged row stride (bytes): 16 rows of a write group hit 16 bank pairs
+    static_assert(RPASS % (TM * 32) == 0 && RPASS % RPP == 0, "a pass is whole wave rows");
+#pragma unroll
+    for (int ep = 0; ep < EP; ++ep) {
+      win_lds_barrier();
+      const unsigned long long e0 = PROBE_NOW();
+      if ((wm * TM * 32) / RPASS == ep) {
+        const int wrow0 = wm * TM * 32 - ep * RPASS;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int row = wrow0 + i * 32 + frow;
+              const int col = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
+              uint2 v;
+              v.x = pack_bf16x2(acc[j][i][4 * g], acc[j][i][4 * g + 1]);
+              v.y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+              *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = v;
+            }
+      }
+      win_lds_barrier();
+      const unsigned long long e1 = PROBE_NOW();
+      pr_ew += e1 - e0;
+      // all of this thread's rows are read in one burst (unconditionally: the LDS latency is paid once, not per row),
+      // the raster decode runs underneath, then the stores go out
+      constexpr int NR = RPASS / RPP;
+      uint4 pk[NR];
+#pragma unroll
+      for (int n = 0; n < NR; ++n) pk[n] = *reinterpret_cast<const uint4*>(smem + (rr + n * RPP) * RS + ch * 16);
+      uint32_t pix[NR];
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const int G = G0 + ep * RPASS + rr + n * RPP;
+        const uint32_t Gc = G < p.Gtot ? G : 0;
+        const uint32_t b = fdiv(Gc, p.div_img);
+        const uint32_t pp = Gc - b * p.img;
+        const uint32_t hh = fdiv(pp, p.div_wp);
+        const uint32_t ww = pp - hh * p.Wp;
+        const bool ok = col_ok && G < p.Gtot && hh < (uint32_t)p.H && ww < (uint32_t)p.W;
+        pix[n] = ok ? (b * p.H + hh) * p.W + ww : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        if (pix[n] != 0xFFFFFFFFu) {
+          *reinterpret_cast<uint4*>(p.dst + (size_t)pix[n] * p.Nout + ncol) = pk[n];
+          if (p.stats) {
+            float q[8];
+            unpack8(pk[n], q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+          }
+        }
+      }
+      pr_er += PROBE_NOW() - e1;
+    }
+  } else
+#pragma unroll
+  for (int slab = 0; slab < BM / 64; ++slab) {
+    win_lds_barrier();
+    if (wm == slab / (TM / 2)) {
+#pragma unroll
+      for (int il = 0; il < 2; ++il) {
+        const int i = (slab % (TM / 2)) * 2 + il;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = il * 32 + frow;
+            const int col = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
+            float4 v = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+            *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
+          }
+      }
+    }
+    win_lds_barrier();
+#pragma unroll 2
+    for (int r = rr; r < 64; r += RPP) {
+      const int G = G0 + slab * 64 + r;
+      bool row_ok = G < p.Gtot;
+      uint32_t pix = 0;
+      if (row_ok) {
+        const uint32_t b = fdiv(G, p.div_img);
+        const uint32_t pp = G - b * p.img;
+        const uint32_t hh = fdiv(pp, p.div_wp);
+        const uint32_t ww = pp - hh * p.Wp;
+        row_ok = hh < (uint32_t)p.H && ww < (uint32_t)p.W;
+        pix = (b * p.H + hh) * p.W + ww;
+      }
+      if (row_ok && col_ok) {
+        const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
+        const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
+        float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const size_t o = (size_t)pix * p.Nout + ncol;
+        if (p.add) {
+          float g[8];
+          unpack8(*reinterpret_cast<const uint4*>(p.add + o), g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += g[e];
+        }
+        const uint4 pk = pack8(f);
+        *reinterpret_cast<uint4*>(p.dst + o) = pk;
+        if (p.stats) {
+          float q[8];
+          unpack8(pk, q);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    // per-thread sums -> LDS [T][16 (+1 pad)] -> CPR*16 threads each add the RPP rows of one (channel group, value):
+    // one barrier, no cross-lane traffic (a shuffle tree here is 32-48 dependent ds_bpermutes)
+    win_lds_barrier();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[tid * 17 + e] = s1[e];
+      red[tid * 17 + 8 + e] = s2[e];
+    }
+    win_lds_barrier();
+    if (tid < CPR * 16) {
+      const int c = tid >> 4, e = tid & 15;
+      float v = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < RPP; ++q) v += red[(q * CPR + c) * 17 + e];
+      const int n = n0 + c * 8 + (e & 7);
+      if (n < p.Nout) p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
+    }
+  }
+  if (p.probe && tid == 0) {
+    unsigned long long* o = p.probe + (size_t)blockIdx.x * 16;
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    o[0] = t_end - pr_t0; o[1] = pr_wait; o[2] = pr_bar; o[3] = pr_comp; o[4] = t_end - pr_loop; o[5] = wall_clock64();
+    o[6] = pr_rbar; o[7] = pr_riss; o[8] = pr_ew; o[9] = pr_er;
+  }
+#undef PROBE_NOW
+#endif   // __HIP_DEVICE_COMPILE__
+}
+
+static unsigned long long* g_win_probe = nullptr;
+extern "C" int mpr_conv_debug_probe(void* buf) {   // 8 x uint64 per workgroup of the next window-kernel launches
+  g_win_probe = (unsigned long long*)buf;
+  return 0;
+}
+static int g_win_on = 1;
+static int g_win_variant = 4;   // measured best: 256 x 128 tile / 2-deep weight ring (N > 64), 256 x 64 / 4-deep (N <= 64)
+extern "C" int mpr_conv_set_window_variant(int v) {
+  const int old = g_win_variant;
+  g_win_variant = v;
+  return old;
+}
+extern "C" int mpr_conv_set_window(int on) {   // tuning / test knob; returns the previous setting
+  const int old = g_win_on;
+  g_win_on = on;
+  return old;
+}
+
+extern "C" {   // (internal to the library: declared in conv_igemm.hip, not in the public header)
+
+// Is (geometry, size) served by the shifted-window kernel?  Shared by the launchers and the stat-row query.
+bool mpr_win_eligible(long long M, int H, int W, int srcC, int Nout, int R, int S, int sh, int sw, int ph, int pw,
+                      long long min_rows) {
+  return g_win_on && R == 3 && S == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && srcC % 64 == 0 && Nout % 8 == 0 &&
+         W >= 2 && W <= 56 && H >= 2 && M >= min_rows && (long long)(M / (H * W)) * (H + 1) * (W + 1) < (1ll << 30);
+}
+
+int mpr_win_tiles(int B, int H, int W) { return ceil_div(B * (H + 1) * (W + 1), 256); }
+
+// src [B,H,W,srcC] (*) panel [Npad128][9*srcC] -> dst [B,H,W,Nout]  (dgrad: mirrored tap shifts)
+int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, const void* add, float* stats, int B, int H,
+                   int W, int srcC, int Nout, hipStream_t st) {
+  WinParams p;
+  p.src = (const bf16_t*)src; p.wpk = (const bf16_t*)wpk; p.dst = (bf16_t*)dst; p.add = (const bf16_t*)add;
+  p.stats = stats;
+  p.H = H; p.W = W; p.C = srcC; p.Nout = Nout;
+  p.Wp = W + 1; p.img = (H + 1) * (W + 1); p.halo = W + 2; p.Gtot = B * p.img; p.wrows = 256 + 2 * p.halo;
+  p.Kgpad = 9 * srcC; p.ncb = srcC / 64;
+  p.src_bytes = (unsigned)((size_t)B * H * W * srcC * 2);
+  p.wpk_bytes = (unsigned)((size_t)((Nout + 127) / 128 * 128) * p.Kgpad * 2);
+  p.div_img = make_fastdiv(p.img); p.div_wp = make_fastdiv(p.Wp);
+  p.probe = g_win_probe;
+  // tile width: 0 (default) = 64 output channels per workgroup with a 4-deep weight ring (8 KB stages);
+  // 1 / 2 = the same with a 2- / 3-deep ring; 3 / 4 = 128 channels (256 x 128 tile) with a 3- / 2-deep ring of 16 KB stages
+  const int BN = ((g_win_variant & 15) >= 3 && Nout > 64) ? 128 : 64;
+  p.ntn = ceil_div(Nout, BN);
+  const int tiles_m = ceil_div(p.Gtot, 256);
+  const size_t wbytes = (size_t)((p.wrows + 7) / 8 * 8) * 128;
+  const size_t lds_pad = (g_win_variant & 16) ? 40 * 1024 : 0;   // experiment: force one workgroup per CU
+  const int g_win_variant_ = g_win_variant & 15;
+  dim3 grid(tiles_m * p.ntn);
+#define MPR_WIN(WM_, WN_, TM_, TN_, ST_, DG_)                                                              \
+  do {                                                                                                     \
+    static bool attr_set = false;                                                                          \
+    if (!attr_set) {                                                                                       \
+      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, DG_>,                      \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      attr_set = true;                                                                                     \
+    }                                                                                                      \
+    const size_t lds = lds_pad + wbytes + (size_t)ST_ * (WN_ * TN_ * 32) * 128;                            \
+    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, DG_><<<grid, 64 * WM_ * WN_, lds, st>>>(p);                   \
+  } while (0)
+#define MPR_WIN2(WM_, WN_, TM_, TN_, ST_) do { if (dgrad) MPR_WIN(WM_, WN_, TM_, TN_, ST_, true); else MPR_WIN(WM_, WN_, TM_, TN_, ST_, false); } while (0)
+  if (BN == 64) {
+    switch (g_win_variant_) {
+      case 1: MPR_WIN2(4, 1, 2, 2, 2); break;
+      case 2: MPR_WIN2(4, 1, 2, 2, 3); break;
+      default: MPR_WIN2(4, 1, 2, 2, 4); break;
+    }
+  } else {
+    switch (g_win_variant_) {
+      case 3: MPR_WIN2(2, 2, 4, 2, 3); break;
+      default: MPR_WIN2(2, 2, 4, 2, 2); break;
+    }
+  }
+#undef MPR_WIN2
+#undef MPR_WIN
+  MPR_LAUNCH_CHECK("conv_win_kernel");
+  return MPR_OK;
+}
+
+}  // extern "C"

@@ -4,6 +4,8 @@ Everything here takes / returns device tensors and enqueues work on torch's curr
 Feature maps are channels-last bf16: ``[B, H, W, C]`` (2-D) or ``[B, L, C]`` (1-D == H of 1).
 PyTorch supplies memory (caching allocator) and streams only -- no torch arithmetic runs here.
 """
+import os
+
 import torch
 
 from . import _native as N
@@ -133,7 +135,51 @@ def grad_target(param):
     tgt = getattr(param, '_mpr_grad', None) if torch.is_tensor(param) else None
     if tgt is not None:
         param._mpr_touched = True
+        _note_arena_stream(tgt.device.index)
     return tgt
+
+
+# ---- streams that write gradient memory behind autograd's back -------------------------------------------
+# A Function that accumulates into grad_target() returns None, so no AccumulateGrad node (and none of the engine's
+# end-of-backward stream synchronisation) covers that write.  Every stream that did such a write -- the stream of
+# the backward node, or the weight-gradient side stream below -- is joined into the caller's stream by ONE
+# end-of-backward callback.
+ASYNC_WGRAD = os.environ.get('MPR_ASYNC_WGRAD', '1') != '0'
+_arena_streams = {}        # raw stream handle -> torch stream object
+_wgrad_side = {}           # raw handle of a compute stream -> its weight-gradient side stream
+_join_queued = [False]
+
+
+def _note_arena_stream(dev, stream=None):
+    h = stream.cuda_stream if stream is not None else torch._C._cuda_getCurrentRawStream(dev)
+    if h not in _arena_streams:
+        _arena_streams[h] = stream if stream is not None else torch.cuda.current_stream()
+    if not _join_queued[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_gradient_streams)
+            _join_queued[0] = True
+        except RuntimeError:        # not inside a backward pass: the caller reads the result on its own stream
+            pass
+
+
+def join_gradient_streams():
+    """Make torch's current stream wait for every stream that wrote optimizer-owned gradient memory."""
+    _join_queued[0] = False
+    cur = torch.cuda.current_stream()
+    for h, s in _arena_streams.items():
+        if h != cur.cuda_stream:
+            cur.wait_stream(s)
+
+
+def _wgrad_stream(dev):
+    """Side stream for weight gradients: they are leaves of the backward graph (nothing downstream reads them
+    before the optimizer), so they run beside the dgrad -> BatchNorm-backward chain -- MFMA-bound work filling the
+    tails and the HBM-bound stretches of that chain."""
+    h = torch._C._cuda_getCurrentRawStream(dev)
+    side = _wgrad_side.get(h)
+    if side is None:
+        side = _wgrad_side[h] = (torch.cuda.current_stream(), torch.cuda.Stream())
+    return side
 
 
 # ------------------------------------------------------------------------------------------ conv
@@ -144,7 +190,7 @@ def conv_fwd(x, wf, g, want_stats):
     y = torch.empty(_like_spatial(x, B, P, Q, g.K), dtype=BF16, device=x.device)
     stats = None
     if want_stats:
-        rows = N.query('mpr_conv_fwd_stat_rows', B, P, Q, g.K, C, g.R, g.S)
+        rows = N.query('mpr_conv_fwd_stat_rows', B, P, Q, g.K, C, *g.tail)
         stats = torch.empty(rows, 2, g.K, dtype=F32, device=x.device)
     N.call('mpr_conv_fwd', x, wf, y, stats, B, H, W, C, g.K, *g.tail)
     return y, stats
@@ -169,7 +215,15 @@ def conv_wgrad(x, dy, g, weight):
     tgt = grad_target(weight)
     if is_krsc(weight):          # the kernel's native [K][R][S][C] result IS the gradient's memory
         if tgt is not None:
-            N.call('mpr_conv_wgrad', x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail)
+            if ASYNC_WGRAD:
+                cur, side = _wgrad_stream(x.device.index)
+                side.wait_stream(cur)
+                N.call('mpr_conv_wgrad', x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail, stream_handle=side.cuda_stream)
+                x.record_stream(side)           # the allocator must not recycle the operands under the side stream
+                dy.record_stream(side)
+                _note_arena_stream(x.device.index, side)
+            else:
+                N.call('mpr_conv_wgrad', x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail)
             return None
         dw = torch.empty_strided(weight.shape, weight.stride(), dtype=F32, device=x.device)
         N.call('mpr_conv_wgrad', x, dy, dw, None, 0, B, H, W, C, g.K, *g.tail)
@@ -531,6 +585,7 @@ class FusedSGD:
         if not self.params:
             return
         self._install()
+        join_gradient_streams()      # (also done by the end-of-backward callback; idempotent)
         live = []
         for i, (p, v) in enumerate(zip(self.params, self._views)):
             g = p.grad

@@ -2,7 +2,10 @@
 import sys, torch
 sys.path.insert(0, '.')
 from multimodal_plankton_recognition_amd import ops, _native as N
+import os
 B = 512
+if os.environ.get('MPR_WIN') == '0':
+    N.query('mpr_conv_set_window', 0)
 shapes = [('l1 3x3 64->64', 56, 64, 64, 3, 1, 1), ('l2 3x3 128->128', 28, 128, 128, 3, 1, 1),
           ('l3 3x3 256->256', 14, 256, 256, 3, 1, 1), ('l4 3x3 512->512', 7, 512, 512, 3, 1, 1),
           ('l2.0 3x3/2 64->128', 56, 64, 128, 3, 2, 1)]

@@ -52,14 +52,24 @@ CONV_CASES = [
     (3, 12, 16, 64, 128, 3, 2, 1),
     (2, 14, 14, 256, 512, 3, 2, 1),
     (9, 20, 12, 64, 64, 3, 2, 1),
+    # 3x3 / stride 1 / pad 1 with 64-channel blocks: the shifted-window kernel (several tiles, widest halo, ragged N
+    # tile, several channel blocks, images smaller than the halo)
+    (2, 56, 56, 64, 64, 3, 1, 1),
+    (3, 9, 7, 64, 192, 3, 1, 1),
+    (5, 7, 7, 256, 128, 3, 1, 1),
+    (40, 4, 3, 128, 64, 3, 1, 1),
+    (1, 2, 2, 64, 8, 3, 1, 1),
 ]
 
 
-@pytest.fixture(params=['regs', 'dma'])
+@pytest.fixture(params=['regs', 'dma', 'win'])
 def igemm_path(request):
-    """Run the conv tests through both implicit-GEMM kernels (register-staged / LDS-DMA ring)."""
+    """Run the conv tests through every implicit-GEMM kernel: register-staged / LDS-DMA ring / LDS-DMA ring with the
+    shifted-window kernel taking the 3x3 stride-1 pad-1 cases."""
     from multimodal_plankton_recognition_amd import _native
-    thr = 0 if request.param == 'dma' else 1 << 30
+    thr = 1 << 30 if request.param == 'regs' else 0
+    old_win = _native.query('mpr_conv_set_window', 1 if request.param == 'win' else 0)
+    request.addfinalizer(lambda: _native.query('mpr_conv_set_window', old_win))
     old = _native.query('mpr_conv_set_dma_min_rows', thr)
     old_w = _native.query('mpr_conv_set_wgrad_dma_min_pixels', thr)
     old_p = _native.query('mpr_conv_set_dgrad_parity', 2)      # parity classes for 1x1 filters too

@@ -20,9 +20,18 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_size_queries_match_documented_tiling():
-    assert _native.query('mpr_conv_fwd_stat_rows', 512, 56, 56, 64, 64, 3, 3) == 512 * 56 * 56 // 256
-    assert _native.query('mpr_conv_fwd_stat_rows', 512, 28, 28, 128, 128, 3, 3) == 512 * 28 * 28 // 128
-    assert _native.query('mpr_conv_fwd_stat_rows', 4, 28, 28, 128, 128, 3, 3) == 4 * 28 * 28 // 128 + 1
+    rows = lambda *a: _native.query('mpr_conv_fwd_stat_rows', *a)
+    # 3x3 / stride 1 / pad 1: shifted-window kernel, 256 positions of the padded raster (H+1) x (W+1) per tile
+    assert rows(512, 56, 56, 64, 64, 3, 3, 1, 1, 1, 1) == -(-512 * 57 * 57 // 256)
+    assert rows(512, 28, 28, 128, 128, 3, 3, 1, 1, 1, 1) == -(-512 * 29 * 29 // 256)
+    old = _native.query('mpr_conv_set_window', 0)
+    try:        # plain LDS-DMA implicit GEMM: 256-row tiles at N = 64, 128-row tiles above
+        assert rows(512, 56, 56, 64, 64, 3, 3, 1, 1, 1, 1) == 512 * 56 * 56 // 256
+        assert rows(512, 28, 28, 128, 128, 3, 3, 1, 1, 1, 1) == 512 * 28 * 28 // 128
+    finally:
+        _native.query('mpr_conv_set_window', old)
+    assert rows(512, 28, 28, 128, 64, 3, 3, 2, 2, 1, 1) == 512 * 28 * 28 // 128          # stride 2: never the window kernel
+    assert rows(4, 28, 28, 128, 128, 3, 3, 1, 1, 1, 1) == 4 * 28 * 28 // 128 + 1          # small problem: register-staged kernel
     assert _native.query('mpr_loss_workspace_floats') >= 1024
 
 
