@@ -289,6 +289,106 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_kernel(const bf16_t* __restri
   }
 }
 
+// The ResNet stem's geometry (3x3 window, stride 2, pad 1, even H and W) as 2x2 source blocks: the block
+// {2i, 2i+1} x {2j, 2j+1} is touched by exactly the four windows (i,j), (i,j+1), (i+1,j), (i+1,j+1), so one thread loads
+// those four (arg-max bytes, pooled gradient) pairs ONCE and finishes all four pixels of the block -- 9 compare-selects
+// per channel and 96 B of window data per 64 B of result, against up to four window look-ups PER PIXEL (and a
+// runtime-geometry loop) in the generic kernel above.  Tap codes are the forward kernel's kh*3 + kw.
+template <int PASS>
+__global__ __launch_bounds__(256) void pool_bn_bwd_s2_kernel(const bf16_t* __restrict__ dy,
+                                                             const unsigned char* __restrict__ idx,
+                                                             const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                             float* __restrict__ partials, bf16_t* __restrict__ dx, PoolGeom g,
+                                                             FastDiv div_cg, FastDiv div_pq, FastDiv div_q) {
+  const int cg = g.C >> 3;
+  const int nthr = blockDim.x;                    // a multiple of cg: the channel group is thread-invariant
+  const int c8 = threadIdx.x % cg;
+  __shared__ float red[PASS == 0 ? 256 : 1][17];
+  float sc[8], sh[8], p1[8], p2[8], p3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = scale[c8 * 8 + e];
+    sh[e] = shift[c8 * 8 + e];
+    if (PASS == 0) { p1[e] = mean[c8 * 8 + e]; p2[e] = invstd[c8 * 8 + e]; p3[e] = 0.f; }
+    else { p1[e] = coef[c8 * 8 + e]; p2[e] = coef[g.C + c8 * 8 + e]; p3[e] = coef[2 * g.C + c8 * 8 + e]; }
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  const unsigned total = (unsigned)g.B * g.P * g.Q * cg;       // 2x2 blocks x channel groups
+  for (unsigned v = blockIdx.x * nthr + threadIdx.x; v < total; v += gridDim.x * nthr) {
+    const unsigned blk = fdiv(v, div_cg);                      // v = blk*cg + c8
+    const unsigned b = fdiv(blk, div_pq);
+    const unsigned rem = blk - b * (unsigned)(g.P * g.Q);
+    const unsigned i = fdiv(rem, div_q);
+    const unsigned j = rem - i * g.Q;
+    // the four windows (clamped addresses; a window beyond the edge contributes nothing)
+    const bool hasj = j + 1 < (unsigned)g.Q, hasi = i + 1 < (unsigned)g.P;
+    const unsigned w00 = ((b * g.P + i) * g.Q + j) * cg + c8;
+    const unsigned w01 = hasj ? w00 + cg : w00, w10 = hasi ? w00 + g.Q * cg : w00;
+    const unsigned w11 = (hasi && hasj) ? w00 + g.Q * cg + cg : w00;
+    const uint2 k00 = reinterpret_cast<const uint2*>(idx)[w00], k01 = reinterpret_cast<const uint2*>(idx)[w01];
+    const uint2 k10 = reinterpret_cast<const uint2*>(idx)[w10], k11 = reinterpret_cast<const uint2*>(idx)[w11];
+    float d00[8], d01[8], d10[8], d11[8];
+    unpack8(reinterpret_cast<const uint4*>(dy)[w00], d00);
+    unpack8(reinterpret_cast<const uint4*>(dy)[w01], d01);
+    unpack8(reinterpret_cast<const uint4*>(dy)[w10], d10);
+    unpack8(reinterpret_cast<const uint4*>(dy)[w11], d11);
+    if (!hasj) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { d01[e] = 0.f; d11[e] = 0.f; }
+    }
+    if (!hasi) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { d10[e] = 0.f; d11[e] = 0.f; }
+    }
+    // source pixels of the block: vec index of (b, 2i + a, 2j + c)
+    const unsigned x00 = ((b * g.H + 2 * i) * g.W + 2 * j) * cg + c8;
+    const unsigned xo[4] = {x00, x00 + cg, x00 + g.W * cg, x00 + g.W * cg + cg};
+    float xf[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) unpack8(reinterpret_cast<const uint4*>(x)[xo[t]], xf[t]);
+    float dz[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned sft = 8 * (e & 3);
+      const unsigned a00 = ((e < 4 ? k00.x : k00.y) >> sft) & 0xff, a01 = ((e < 4 ? k01.x : k01.y) >> sft) & 0xff;
+      const unsigned a10 = ((e < 4 ? k10.x : k10.y) >> sft) & 0xff, a11 = ((e < 4 ? k11.x : k11.y) >> sft) & 0xff;
+      dz[0][e] = a00 == 4 ? d00[e] : 0.f;
+      dz[1][e] = (a00 == 5 ? d00[e] : 0.f) + (a01 == 3 ? d01[e] : 0.f);
+      dz[2][e] = (a00 == 7 ? d00[e] : 0.f) + (a10 == 1 ? d10[e] : 0.f);
+      dz[3][e] = ((a00 == 8 ? d00[e] : 0.f) + (a01 == 6 ? d01[e] : 0.f)) + ((a10 == 2 ? d10[e] : 0.f) + (a11 == 0 ? d11[e] : 0.f));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dz[t][e] = round_bf16(fmaf(xf[t][e], sc[e], sh[e])) > 0.f ? dz[t][e] : 0.f;
+      if (PASS == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += dz[t][e]; s2[e] += dz[t][e] * (xf[t][e] - p1[e]) * p2[e]; }
+      } else {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(p1[e], dz[t][e], fmaf(p2[e], xf[t][e], p3[e]));
+        reinterpret_cast<uint4*>(dx)[xo[t]] = pack8(o);
+      }
+    }
+  }
+  if (PASS == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cg * 16; i += nthr) {
+      const int gg = i >> 4, e = i & 15;
+      float a = 0.f;
+      for (int t = gg; t < nthr; t += cg) a += red[t][e];
+      partials[((size_t)blockIdx.x * 2 + (e >> 3)) * g.C + gg * 8 + (e & 7)] = a;
+    }
+  }
+}
+
 static inline int ew_grid(long long n, int block) {
   long long g = (n + block - 1) / block;
   return (int)(g < 4096 ? (g < 1 ? 1 : g) : 4096);
@@ -347,6 +447,20 @@ int mpr_pool_bn_bwd(int pass, const void* dy_pooled, const void* idx, const void
   MPR_REQUIRE((SH == 1 || SH == 2) && (SW == 1 || SW == 2), "mpr_pool_bn_bwd: strides must be 1 or 2");
   MPR_REQUIRE(RW <= 2 * SW, "mpr_pool_bn_bwd: window width %d > 2 * stride %d is not supported", RW, SW);
   const FastDiv dcg = make_fastdiv(C / 8), dhw = make_fastdiv(H * W), dw = make_fastdiv(W);
+  if (RH == 3 && RW == 3 && SH == 2 && SW == 2 && PH == 1 && PW == 1 && H % 2 == 0 && W % 2 == 0) {
+    // the image stem: 2x2 source blocks, every window loaded once
+    const FastDiv dpq = make_fastdiv(g.P * g.Q), dq = make_fastdiv(g.Q);
+    if (pass == 0)
+      pool_bn_bwd_s2_kernel<0><<<grid, block, 0, st>>>((const bf16_t*)dy_pooled, (const unsigned char*)idx,
+                                                       (const bf16_t*)x, scale, shift, mean, invstd, nullptr, partials,
+                                                       nullptr, g, dcg, dpq, dq);
+    else
+      pool_bn_bwd_s2_kernel<1><<<grid, block, 0, st>>>((const bf16_t*)dy_pooled, (const unsigned char*)idx,
+                                                       (const bf16_t*)x, scale, shift, nullptr, nullptr, coef, nullptr,
+                                                       (bf16_t*)dx, g, dcg, dpq, dq);
+    MPR_LAUNCH_CHECK("pool_bn_bwd_s2_kernel");
+    return MPR_OK;
+  }
   if (pass == 0)
     pool_bn_bwd_kernel<0><<<grid, block, 0, st>>>((const bf16_t*)dy_pooled, (const unsigned char*)idx, (const bf16_t*)x,
                                                   scale, shift, mean, invstd, nullptr, partials, nullptr, g, dcg, dhw, dw);
