@@ -36,6 +36,32 @@ def synthetic_batch(B, T, device, seed):
     return {'image': image, 'profile': profile, 'image_shape': image_shape, 'profile_len': profile_len}
 
 
+def isolated_conv_rate(B, dev):
+    """The dominant kernel with nothing else on the GPU: forward + data gradient of the four 3x3 body convolutions
+    of ResNet-18 at the bench batch (event-timed on the current stream, 5 launches each after 2 warm-up)."""
+    from multimodal_plankton_recognition_amd import ops
+    tot_ms, tot_flop = 0.0, 0.0
+    for H, C in ((56, 64), (28, 128), (14, 256), (7, 512)):
+        g = ops.ConvGeom((C, C, 3, 3), 1, 1)
+        w = torch.randn(C, C, 3, 3, device=dev) * 0.05
+        wf, wd = ops.packed_weights(w, g)
+        x = torch.randn(B, H, H, C, device=dev).to(torch.bfloat16)
+        for fn in (lambda: ops.conv_fwd(x, wf, g, True), lambda: ops.conv_dgrad(x, wd, g, x.shape)):
+            for _ in range(2):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            tot_ms += a.elapsed_time(b) / 5
+            tot_flop += 2.0 * B * H * H * C * C * 9
+    rate = tot_flop / (tot_ms * 1e-3) / 1e12
+    return {'achieved': round(rate, 2), 'frac': round(rate / MFMA_BF16_PEAK_TFLOPS, 4), 'unit': 'TFLOP/s',
+            'avg_launch_us': round(tot_ms * 1e3 / 8, 2)}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary (scripts/prof_pmc.sh + scripts/pmc_summary.py run
     this same command under rocprofv3 --pmc; a process cannot read its own counters), or None."""
@@ -179,7 +205,7 @@ def main():
                        'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'loss': round(loss_val, 5)},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma_kernel (forward + data-gradient instantiations, image branch)',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_win_kernel + conv_igemm_dma_kernel (LDS-DMA implicit-GEMM conv, forward + data-gradient instantiations, image branch)',
                          'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                          'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, '
@@ -190,7 +216,10 @@ def main():
                          'wgrad_kernel': {'name': 'conv_wgrad_dma_kernel',
                                           'achieved': round(w_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
                                           'launches': n_w, 'share_of_step_time': round(ms_w / args.steps / ms_per_step, 3)},
-                         'note': 'event-timed on the launch stream while the profile branch runs on a second stream'},
+                         'alone': isolated_conv_rate(B, dev),
+                         'note': 'achieved / avg_launch_us: event-timed on the launch stream INSIDE the timed steps, i.e. while '
+                                 'the profile branch and the weight-gradient kernels run beside it on other streams; '
+                                 '"alone" is the same kernel on the four ResNet-18 body shapes with the GPU to itself'},
         }
         if world == 1 and not args.no_cpu_baseline:
             # host share of a 1-GPU box is 16 cores (the node reports all of them): never oversubscribe

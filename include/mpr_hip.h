@@ -55,7 +55,7 @@ int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S, int 
  * shifted-window kernel (conv_win.hip: the haloed activation window is loaded once per 64-channel block and all nine
  * taps read it at shifted LDS rows); 0 switches it off (tests / comparisons); returns the previous setting */
 int mpr_conv_set_window(int on);
-/* tile / weight-ring variant of the shifted-window kernel (tuning knob, see conv_win.hip; default 4) */
+/* tile / weight-ring variant of the shifted-window kernel (tuning knob, see conv_win.hip; default 5) */
 int mpr_conv_set_window_variant(int v);
 /* rows (B*P*Q) from which the LDS-DMA ring kernel replaces the register-staged one (default 16384);
  * returns the previous threshold */

@@ -17,19 +17,29 @@ __global__ __launch_bounds__(1024) void bn_finalize_stats_kernel(
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
     float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
     float* __restrict__ invstd_out, int C) {
+  // (256-thread blocks -- 32 channels x 8 partial-row lanes, 4 waves: small enough to start beside the long-running
+  //  conv workgroups of a concurrent stream instead of queueing for a whole CU's worth of wave slots and registers)
   __shared__ double red[2][32][33];
+  const int PL = blockDim.x >> 5;
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int i = pl; i < nparts; i += 32) {
-      s1 += (double)partials[((size_t)i * 2) * C + c];
-      s2 += (double)partials[((size_t)i * 2 + 1) * C + c];
+    for (int i0 = pl; i0 < nparts; i0 += PL * 8) {     // 16 independent loads in flight
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + PL * u;
+        a[u] = i < nparts ? partials[((size_t)i * 2) * C + c] : 0.f;
+        b[u] = i < nparts ? partials[((size_t)i * 2 + 1) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
     }
   red[0][pl][threadIdx.x & 31] = s1;
   red[1][pl][threadIdx.x & 31] = s2;
   __syncthreads();
   if (pl == 0 && c < C) {
-    for (int i = 1; i < 32; ++i) { s1 += red[0][i][threadIdx.x]; s2 += red[1][i][threadIdx.x]; }
+    for (int i = 1; i < PL; ++i) { s1 += red[0][i][threadIdx.x]; s2 += red[1][i][threadIdx.x]; }
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -200,14 +210,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int accumulate, float* __restrict__ coef, int C) {
   __shared__ double red[2][32][33];
+  const int PL = blockDim.x >> 5;                    // partial-row lanes (8 at the 256-thread launch, see above)
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int i0 = pl; i0 < nparts; i0 += 32 * 8) {   // 16 independent loads in flight (the chain is latency-bound)
+    for (int i0 = pl; i0 < nparts; i0 += PL * 8) {   // 16 independent loads in flight (the chain is latency-bound)
       float a[8], b[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = i0 + 32 * u;
+        const int i = i0 + PL * u;
         a[u] = i < nparts ? partials[((size_t)i * 2) * C + c] : 0.f;
         b[u] = i < nparts ? partials[((size_t)i * 2 + 1) * C + c] : 0.f;
       }
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
   red[1][pl][threadIdx.x & 31] = s2;
   __syncthreads();
   if (pl == 0 && c < C) {
-    for (int i = 1; i < 32; ++i) { s1 += red[0][i][threadIdx.x]; s2 += red[1][i][threadIdx.x]; }
+    for (int i = 1; i < PL; ++i) { s1 += red[0][i][threadIdx.x]; s2 += red[1][i][threadIdx.x]; }
     const float sum_dz = (float)s1, sum_dzx = (float)s2;
     const float g = gamma ? gamma[c] : 1.f, is = invstd[c], mu = mean[c];
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sum_dzx : sum_dzx;
@@ -295,7 +306,7 @@ int mpr_bn_finalize_stats(const float* partials, int nparts, long long count, co
                           const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                           float* scale, float* shift, float* mean, float* invstd, int C, void* stream) {
   MPR_REQUIRE(partials && scale && shift && mean && invstd, "mpr_bn_finalize_stats: null pointer");
-  bn_finalize_stats_kernel<<<ceil_div(C, 32), 1024, 0, (hipStream_t)stream>>>(
+  bn_finalize_stats_kernel<<<ceil_div(C, 32), 256, 0, (hipStream_t)stream>>>(
       partials, nparts, (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean,
       invstd, C);
   MPR_LAUNCH_CHECK("bn_finalize_stats_kernel");
@@ -348,7 +359,7 @@ int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float*
 int mpr_bn_bwd_finalize(const float* partials, int nparts, long long count, const float* gamma, const float* mean,
                         const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef, int C,
                         void* stream) {
-  bn_bwd_finalize_kernel<<<ceil_div(C, 32), 1024, 0, (hipStream_t)stream>>>(
+  bn_bwd_finalize_kernel<<<ceil_div(C, 32), 256, 0, (hipStream_t)stream>>>(
       partials, nparts, (float)count, gamma, mean, invstd, dgamma, dbeta, accumulate, coef, C);
   MPR_LAUNCH_CHECK("bn_bwd_finalize_kernel");
   return MPR_OK;

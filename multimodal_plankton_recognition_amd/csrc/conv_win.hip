@@ -390,7 +390,7 @@ extern "C" int mpr_conv_debug_probe(void* buf) {   // 8 x uint64 per workgroup o
   return 0;
 }
 static int g_win_on = 1;
-static int g_win_variant = 4;   // measured best: 256 x 128 tile / 2-deep weight ring (N > 64), 256 x 64 / 4-deep (N <= 64)
+static int g_win_variant = 5;   // measured best: 256 x 128 tile on 8 waves / 2-deep weight ring (N > 64), 256 x 64 / 4-deep (N <= 64)
 extern "C" int mpr_conv_set_window_variant(int v) {
   const int old = g_win_variant;
   g_win_variant = v;
@@ -426,8 +426,10 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
   p.wpk_bytes = (unsigned)((size_t)((Nout + 127) / 128 * 128) * p.Kgpad * 2);
   p.div_img = make_fastdiv(p.img); p.div_wp = make_fastdiv(p.Wp);
   p.probe = g_win_probe;
-  // tile width: 0 (default) = 64 output channels per workgroup with a 4-deep weight ring (8 KB stages);
-  // 1 / 2 = the same with a 2- / 3-deep ring; 3 / 4 = 128 channels (256 x 128 tile) with a 3- / 2-deep ring of 16 KB stages
+  // variants: 0 = 64 output channels per workgroup with a 4-deep weight ring (8 KB stages); 1 / 2 = the same with a
+  // 2- / 3-deep ring; 3 / 4 = 128 channels (256 x 128 tile, 4 waves of 128 x 64) with a 3- / 2-deep ring of 16 KB
+  // stages; 5 (default) / 6 = 256 x 128 on 8 waves of 64 x 64 with a 2- / 3-deep ring.  N <= 64 always takes the
+  // 256 x 64 tile (4 waves of 64 x 64; 4-deep ring unless variant 1 / 2).
   const int BN = ((g_win_variant & 15) >= 3 && Nout > 64) ? 128 : 64;
   p.ntn = ceil_div(Nout, BN);
   const int tiles_m = ceil_div(p.Gtot, 256);
@@ -456,6 +458,8 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
   } else {
     switch (g_win_variant_) {
       case 3: MPR_WIN2(2, 2, 4, 2, 3); break;
+      case 5: MPR_WIN2(4, 2, 2, 2, 2); break;     // 8 waves of 64 x 64: the instruction-bound pro/epilogue on twice the waves
+      case 6: MPR_WIN2(4, 2, 2, 2, 3); break;
       default: MPR_WIN2(2, 2, 4, 2, 2); break;
     }
   }

@@ -178,7 +178,13 @@ def _wgrad_stream(dev):
     h = torch._C._cuda_getCurrentRawStream(dev)
     side = _wgrad_side.get(h)
     if side is None:
-        side = _wgrad_side[h] = (torch.cuda.current_stream(), torch.cuda.Stream())
+        # lowest priority: the side stream must only FILL what the dependent chain leaves free -- at equal priority its
+        # 200-us kernels hold every CU while the chain's 5-us BatchNorm finalize kernels queue behind them
+        try:
+            low = int(os.environ.get('MPR_WGRAD_PRIORITY', torch.cuda.Stream.priority_range()[0]))
+        except Exception:
+            low = 0
+        side = _wgrad_side[h] = (torch.cuda.current_stream(), torch.cuda.Stream(priority=low))
     return side
 
 

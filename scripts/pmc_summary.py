@@ -35,15 +35,15 @@ for k, a in agg.items():
               'hbm_bytes_per_launch': (rd + wr) / a['launches']}
 
 
-def family(prefix):
-    ks = [k for k in out if k.startswith(prefix)]
+def family(*prefixes):
+    ks = [k for k in out if k.startswith(prefixes)]
     n = sum(out[k]['launches_per_step'] for k in ks)
     b = sum(out[k]['read_bytes_per_step'] + out[k]['write_bytes_per_step'] for k in ks)
     return {'launches_per_step': n, 'hbm_bytes_per_launch': b / max(n, 1), 'hbm_bytes_per_step': b}
 
 
 summary = {'tag': tag, 'workload': 'bench.py C3 step, batch 512, one MI355X', 'correction': 'read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB',
-           'conv_igemm_dma_kernel': family('conv_igemm_dma_kernel'), 'conv_wgrad_dma_kernel': family('conv_wgrad_dma_kernel'),
+           'conv_igemm_dma_kernel': family('conv_igemm_dma_kernel', 'conv_win_kernel'), 'conv_wgrad_dma_kernel': family('conv_wgrad_dma_kernel'),
            'whole_step_hbm_bytes': sum(v['read_bytes_per_step'] + v['write_bytes_per_step'] for v in out.values()),
            'kernels': out}
 json.dump(summary, open(f'profiles/{tag}_pmc_traffic.json', 'w'), indent=1)
