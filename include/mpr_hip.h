@@ -74,8 +74,19 @@ int mpr_conv_debug_stamps(void* buf);
 /* timing experiments only: the shifted-window kernel writes, per workgroup, wave 0's shader-clock sums {total,
  * waiting for DMA, waiting at the barrier, computing, epilogue, end time (100 MHz), -, -} into buf[8 * workgroups] */
 int mpr_conv_debug_probe(void* buf);
+/* timing experiments only: as mpr_conv_debug_stamps, for the LDS-DMA weight-gradient kernel */
+int mpr_conv_debug_wgrad_stamps(void* buf);
+/* timing experiments only: the sliding-window weight-gradient kernel writes wave 0's shader-clock sums {main loop,
+ * waiting for DMA, barrier, issuing DMA, computing, chunks, -, -} per workgroup into buf[8 * workgroups] */
+int mpr_conv_debug_wgrad_probe(void* buf);
 /* output pixels (B*P*Q) from which the LDS-DMA weight-gradient kernel is used (default 16384) */
 int mpr_conv_set_wgrad_dma_min_pixels(int pixels);
+/* workgroups the split over pixels of the LDS-DMA weight-gradient kernel aims at (default 512 = one full round of
+ * 2 per CU); returns the previous value */
+int mpr_conv_set_wgrad_target_wgs(int n);
+/* weight gradients of 3x3 / stride 1 / pad 1 convolutions (C, K multiples of 64) run on the sliding-window kernel
+ * (conv_wgrad_win.hip); 0 switches it off (tests / comparisons); returns the previous setting */
+int mpr_conv_set_wgrad_window(int on);
 int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may be NULL */, int B, int H, int W,
                  int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
 int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add /* may be NULL */, int B, int H,

@@ -19,6 +19,7 @@ struct WgradParams {
   int Mpix, Ng, cps, ntm, ntn, ngroups;
   unsigned rowpat;              // sum_r 1 << (r*S): one bit per filter row (tap masks of the LDS-DMA kernel)
   FastDiv div_pq, div_q, div_c, div_s;
+  unsigned long long* stamps;   // timing experiments: 4 x uint64 (100 MHz) per workgroup of the LDS-DMA kernel, or NULL
 };
 
 template <int WM, int WN>
@@ -222,6 +223,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   int pix_end = pix_begin + p.cps * BKP;
   if (pix_end > p.Mpix) pix_end = p.Mpix;
   const int nchunks = (pix_end - pix_begin + BKP - 1) / BKP;
+#define WG_STAMP(k) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+  WG_STAMP(0);
 
   // ---- lane-constant DMA coordinates
   uint32_t a_off[A_IT];
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
     b_rd[t] = A_BYTES + rowl * BSTR + (((wn * 2 + t) ^ wg_seg_xor<CB>(lq)) << 6) + inseg;
   }
 
+  WG_STAMP(1);
   if (nchunks > 0) {
     decode_chunk(0);
     issue_chunk(0);
@@ -342,30 +346,44 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
       decode_chunk(ci + 2);
     }
     const unsigned char* a = smem + (ci & 1) * STAGE;
+    // software-pipelined k-steps (as conv_igemm.hip): the transposing reads of step ks+1 are in flight, in their own
+    // registers, while the four MFMAs of step ks run
+    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x4 ra[2][2][2], rb[2][2][2];      // [buffer][tile][half]
+    auto load_frags = [&](int buf, int ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const unsigned char* pa = a + a_rd[t] + ks * 16 * ASTR;
+        const unsigned char* pb = a + b_rd[t] + ks * 16 * BSTR;
+        ra[buf][t][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa));
+        ra[buf][t][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + 4 * ASTR));
+        rb[buf][t][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb));
+        rb[buf][t][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb + 4 * BSTR));
+      }
+    };
+    load_frags(0, 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1;
+      if (ks < 3) load_frags(cur ^ 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
       bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        typedef s16x4 __attribute__((address_space(3))) * lds_v4;
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const unsigned char* pa = a + a_rd[t] + ks * 16 * ASTR;
-        const unsigned char* pb = a + b_rd[t] + ks * 16 * BSTR;
-        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa));
-        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + 4 * ASTR));
-        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb));
-        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb + 4 * BSTR));
-        af[t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-        bfr[t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        af[t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(ra[cur][t][0], ra[cur][t][1], 0, 1, 2, 3, 4, 5, 6, 7));
+        bfr[t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(rb[cur][t][0], rb[cur][t][1], 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
+  WG_STAMP(2);
   const int ln = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -378,7 +396,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
         if (k < p.K && n < p.Ng) atomicAdd(p.dw + (size_t)k * p.Ng + n, acc[i][j][e]);
       }
     }
+  WG_STAMP(3);
+#undef WG_STAMP
 #endif   // __HIP_DEVICE_COMPILE__
+}
+
+static int g_wgrad_target_wgs = 512;
+extern "C" int mpr_conv_set_wgrad_target_wgs(int n) {   // tuning knob; returns the previous value
+  const int old = g_wgrad_target_wgs;
+  g_wgrad_target_wgs = n;
+  return old;
+}
+static unsigned long long* g_wgrad_stamps = nullptr;
+extern "C" int mpr_conv_debug_wgrad_stamps(void* buf) {
+  g_wgrad_stamps = (unsigned long long*)buf;
+  return 0;
 }
 
 // [K][(r,s,c)] fp32 -> OIHW fp32 (optionally accumulating into an existing gradient)
@@ -398,6 +430,12 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ src, float* __rest
 static int g_wgrad_dma_min_pix = 16384;
 
 extern "C" {
+
+// sliding-window kernel for 3x3 / stride 1 / pad 1 (conv_wgrad_win.hip)
+bool mpr_wgw_eligible(long long Mpix, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
+                      long long min_pix);
+int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W, int C, int K, int target_wgs,
+                   hipStream_t st);
 
 int mpr_conv_set_wgrad_dma_min_pixels(int pixels) {   // tuning / test knob; returns the previous value
   const int old = g_wgrad_dma_min_pix;
@@ -421,6 +459,7 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   p.H = H; p.W = W; p.C = C; p.K = K; p.P = P; p.Q = Q; p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
   p.Mpix = B * P * Q; p.Ng = R * S * C;
   p.div_pq = make_fastdiv(P * Q); p.div_q = make_fastdiv(Q); p.div_c = make_fastdiv(C); p.div_s = make_fastdiv(S);
+  p.stamps = g_wgrad_stamps;
   p.rowpat = 0;
   for (int r = 0; r < R && r * S < 32; ++r) p.rowpat |= 1u << (r * S);
   p.x_bytes = (unsigned)((size_t)B * H * W * C * 2);
@@ -429,6 +468,21 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   // weight); `accumulate` then adds into what is there instead of zeroing it first
   if (dw_oihw || !accumulate) MPR_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)K * p.Ng, st));
 
+  if (mpr_wgw_eligible(p.Mpix, H, W, C, K, R, S, sh, sw, ph, pw, g_wgrad_dma_min_pix)) {
+    // 3x3 / stride 1 / pad 1: sliding-window kernel (conv_wgrad_win.hip)
+    void* tok = mpr_prof_begin(2, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
+    mpr_prof_bytes(tok, (double)p.x_bytes + (double)p.dy_bytes + 4.0 * K * p.Ng);
+    const int rc = mpr_wgw_launch(x, dy, workspace, B, H, W, C, K, g_wgrad_target_wgs, st);
+    mpr_prof_end(tok, st);
+    if (rc != MPR_OK) return rc;
+    if (dw_oihw) {
+      const int total = K * C * R * S;
+      const int g2 = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
+      wgrad_unpack_kernel<<<g2, 256, 0, st>>>(workspace, dw_oihw, K, C, R, S, accumulate);
+      MPR_LAUNCH_CHECK("wgrad_unpack_kernel");
+    }
+    return MPR_OK;
+  }
   if (C % 64 == 0 && K % 64 == 0 && R * S <= 31 && p.Mpix >= g_wgrad_dma_min_pix) {
     // LDS-DMA ring kernel: 64-pixel chunks, 2 workgroups per CU
     const int WM = K <= 64 ? 1 : 2;
@@ -437,7 +491,10 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
     p.ntm = ceil_div(K, BM); p.ntn = ceil_div(p.Ng, BN);
     const int tiles = p.ntm * p.ntn;
     const int total_chunks = ceil_div(p.Mpix, 64);
-    int nsplit = ceil_div(768, tiles);
+    // ONE round of workgroups: 2 fit a CU (64 KB of LDS each), 512 slots on the chip.  A grid of 768 (1.5 rounds) left
+    // the second round half empty -- measured: 360-400 of 512 slots alive on average, 25 % of the kernel time.
+    int nsplit = g_wgrad_target_wgs / tiles;
+    while (nsplit > 8 && (p.ntm * nsplit) % 8) --nsplit;                          // whole XCD groups of 8 (no padding WGs)
     if (nsplit > ceil_div(total_chunks, 4)) nsplit = ceil_div(total_chunks, 4);   // >= 4 chunks per split
     if (nsplit < 1) nsplit = 1;
     p.cps = ceil_div(total_chunks, nsplit);

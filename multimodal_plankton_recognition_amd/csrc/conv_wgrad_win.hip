@@ -1,0 +1,353 @@
+// Weight gradient of 3x3 / stride 1 / pad 1 convolutions on a sliding activation window -- the weight-gradient
+// counterpart of conv_win.hip (the 13 body convolutions of ResNet-18 behind src/image_encoder.py:24).
+//
+//   dW[k][(r,s)][c] = sum over pixels G of dy[G][k] * x[G + (r-1)*(W+1) + (s-1)][c]
+//
+// in the padded raster of conv_win.hip (G = (b*(H+1) + h)*(W+1) + w: one zero column after every image row, one zero
+// row after every image, so the tap shift is LINEAR in G and every out-of-image neighbour is a pad position that the
+// DMA zero-fills).  The plain LDS-DMA kernel (conv_wgrad.hip) gathers a fresh [64 pixels][128 (tap, channel)] tile
+// per tap block -- 32 KB of operands per 2.1 MFLOP, which pins it to the CU's global->LDS fill rate.  Here a workgroup
+// owns ALL NINE taps of a (64*KH output channels) x (64 input channels) block: the 64 input channels of the pixels
+// live in a 256-row LDS ring that slides along the raster (64 new rows per 64-pixel chunk), the nine taps read it at
+// shifted rows, and only dy streams beside it: 16-24 KB per 4.7-9.4 MFLOP chunk (295-393 FLOP/B).
+//
+// Workgroup: 3 (filter row r) x 2 (channel half) x KH (64-wide slab of output channels) waves; a wave accumulates
+// 2 x 3 MFMA tiles: [64 output channels] x [3 taps (r, 0..2) x 32 channels].  Both operands are pixel-major in
+// memory while the contraction runs over pixels, so fragments come from ds_read_b64_tr_b16 as in conv_wgrad.hip.
+// The pixel axis is split over workgroups; partial tiles are added into the [K][R][S][C] gradient with fp32 atomics.
+#include "common.h"
+
+struct WgwParams {
+  const bf16_t* x;     // [B,H,W,C]
+  const bf16_t* dy;    // [B,H,W,K]
+  float* dw;           // [K][9*C]
+  int H, W, C, K;
+  int Wp, img, Gtot, halo8;   // W+1, (H+1)*(W+1), B*img, (W+2) rounded up to 8
+  int Ng, ncb, nkt, cps, total_chunks;
+  unsigned x_bytes, dy_bytes;
+  FastDiv div_img, div_wp;
+  int dbg;   // timing experiments: bit 0 = skip the atomic epilogue
+  unsigned long long* probe;   // timing experiments: 8 x uint64 shader-clock sums per workgroup (wave 0), or NULL
+};
+
+template <int N>
+__device__ __forceinline__ void wgw_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Transposing LDS read as INLINE ASM.  Through the builtin, hipcc cannot tell the read from the LDS-DMA writes in
+// flight and guards it with s_waitcnt vmcnt(0) -- i.e. every chunk would wait for the NEXT chunk's DMA it has just
+// issued, and nothing would overlap.  The asm form is invisible to that pass; completion is handled by hand:
+// wgw_lds_wait() is the s_waitcnt lgkmcnt(0) and carries the destination registers as in/out operands, so every
+// consumer is ordered behind it.
+__device__ __forceinline__ s16x4 wgw_read_tr(uint32_t lds_addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+  return v;
+}
+
+template <int KH>
+__global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = 6 * KH;
+  constexpr int RING = 256;                    // x ring rows (128 B each: 64 channels)
+  constexpr int XBYTES = RING * 128;
+  constexpr int DROW = 128 * KH;               // dy stage row bytes (64*KH output channels)
+  constexpr int DSTAGE = 64 * DROW;
+  constexpr int D_INSTR = DSTAGE / 1024;       // 8*KH DMA instructions per dy chunk
+  constexpr int D_IT = (D_INSTR + NW - 1) / NW;
+  constexpr int XI_IT = (24 + NW - 1) / NW;    // initial window: up to 64 + 2*64 rows = 24 instructions
+  constexpr int XC_IT = (8 + NW - 1) / NW;     // per chunk: 64 new rows = 8 instructions
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [x ring 32 KB][dy stage 0][dy stage 1]
+  unsigned char* const dyst = smem + XBYTES;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address of smem
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid % 3, wh = (wid / 3) & 1, wk = wid / 6;      // filter row, channel half, output-channel slab
+  // consecutive blocks share the pixel range (their dy / x rows come from the same L2 lines)
+  const int cb = blockIdx.x % p.ncb;
+  const int kt = (blockIdx.x / p.ncb) % p.nkt;
+  const int split = blockIdx.x / (p.ncb * p.nkt);
+  const int c0 = split * p.cps;
+  int c1 = c0 + p.cps;
+  if (c1 > p.total_chunks) c1 = p.total_chunks;
+  if (c0 >= c1) return;
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+
+  // raster position -> source pixel (or "pad": zero-filled by an out-of-range offset)
+  auto pixel_of = [&](int G, uint32_t& pix) -> bool {
+    if (G < 0 || G >= p.Gtot) return false;
+    const uint32_t b = fdiv(G, p.div_img);
+    const uint32_t pp = G - b * p.img;
+    const uint32_t hh = fdiv(pp, p.div_wp);
+    const uint32_t ww = pp - hh * p.Wp;
+    pix = (b * p.H + hh) * p.W + ww;
+    return hh < (uint32_t)p.H && ww < (uint32_t)p.W;
+  };
+  // x rows [G8, G8+8) (G8 a multiple of 8) -> ring rows G8 & 255 ...; lane -> (row lane/8, physical chunk lane%8),
+  // 64-B segment swizzle on the source side: logical chunk = ((pc >> 2) ^ ((row >> 1) & 1)) << 2 | (pc & 3)
+  auto x_off = [&](int G8) -> uint32_t {
+    const int G = G8 + (lane >> 3);
+    const int row = G & (RING - 1);
+    const int pc = lane & 7;
+    const int lc = (((pc >> 2) ^ ((row >> 1) & 1)) << 2) | (pc & 3);
+    uint32_t pix;
+    return pixel_of(G, pix) ? pix * (uint32_t)(2 * p.C) + (uint32_t)((cb * 64 + lc * 8) * 2) : 0xFFFFFFF0u;
+  };
+  auto fire_x8 = [&](int G8, uint32_t v) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rs_x, (__attribute__((address_space(3))) void*)(smem + (G8 & (RING - 1)) * 128), 16, v, 0, 0, 0);
+  };
+  auto issue_x8 = [&](int G8) { fire_x8(G8, x_off(G8)); };
+  // dy rows of chunk ci -> stage ci & 1: instruction I covers 1024 / DROW rows
+  auto dy_off = [&](int ci, int I) -> uint32_t {
+    constexpr int CH = DROW / 16;                       // 16-B chunks per row (8 or 16)
+    const int q = I * 64 + lane;
+    const int row = q / CH, pc = q % CH;
+    const int key = CH == 16 ? (row & 3) : ((row >> 1) & 1);
+    const int lc = (((pc >> 2) ^ key) << 2) | (pc & 3);
+    uint32_t pix;
+    return pixel_of(ci * 64 + row, pix) ? pix * (uint32_t)(2 * p.K) + (uint32_t)((kt * 64 * KH + lc * 8) * 2)
+                                        : 0xFFFFFFF0u;
+  };
+  // The source offsets of a chunk's DMA (two fastdivs per lane and instruction) are computed ONE CHUNK AHEAD, underneath
+  // the MFMAs of the previous chunk; after the barrier only the buffer_load ... lds instructions themselves remain.
+  // (Computed right there they cost every wave ~900 cycles with the matrix pipe idle: all waves sit at the same point.)
+  uint32_t vx[XC_IT], vd[D_IT];
+  auto prep_chunk = [&](int ci) {       // chunk ci: its 64 leading-edge ring rows and its dy rows
+    const int lo = ci * 64 + p.halo8;
+#pragma unroll
+    for (int j = 0; j < XC_IT; ++j) {
+      const int I = wid + j * NW;
+      vx[j] = (8 % NW == 0 || I < 8) ? x_off(lo + 8 * I) : 0xFFFFFFF0u;
+    }
+#pragma unroll
+    for (int j = 0; j < D_IT; ++j) {
+      const int I = wid + j * NW;
+      vd[j] = (D_INSTR % NW == 0 || I < D_INSTR) ? dy_off(ci, I) : 0xFFFFFFF0u;
+    }
+  };
+  auto fire_chunk = [&](int ci) {
+    const int lo = ci * 64 + p.halo8;
+    unsigned char* st = dyst + (ci & 1) * DSTAGE;
+#pragma unroll
+    for (int j = 0; j < XC_IT; ++j) {
+      const int I = wid + j * NW;
+      if (8 % NW == 0 || I < 8) fire_x8(lo + 8 * I, vx[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < D_IT; ++j) {
+      const int I = wid + j * NW;
+      if (D_INSTR % NW == 0 || I < D_INSTR)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(st + I * 1024), 16, vd[j],
+                                                 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][3];     // [m-tile of 32 output channels][tap s]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][s][e] = 0.f;
+
+  // transposing-read lane geometry (conv_wgrad.hip): a 16-lane group reads a 4 (pixel) x 16 (column) block
+  const int g16 = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+  const int rowl = 8 * (g16 >> 1) + lq;                        // pixel row inside a 16-deep k-step (+4: second read)
+  const int inseg = (16 * (g16 & 1) + 4 * lp) * 2;             // byte inside a 64-B segment
+  // dy fragment offsets inside a stage (pixel rows are chunk-local: key is lane-constant)
+  uint32_t a_rd[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int seg = wk * 2 + i;                                // 64-B segment = 32 output channels
+    const int key = KH == 2 ? (lq & 3) : ((lq >> 1) & 1);
+    a_rd[i] = rowl * DROW + ((seg ^ key) << 6) + inseg;
+  }
+
+  // ---- prologue: window of the first chunk + its dy
+  {
+    const int lo = c0 * 64 - p.halo8, hi = c0 * 64 + 64 + p.halo8;
+#pragma unroll
+    for (int j = 0; j < XI_IT; ++j) {
+      const int G8 = lo + 8 * (wid + j * NW);
+      if (G8 < hi) issue_x8(G8);
+    }
+    prep_chunk(c0);          // (only its dy half is used: the window above already holds chunk c0's rows)
+    {
+      unsigned char* st = dyst + (c0 & 1) * DSTAGE;
+#pragma unroll
+      for (int j = 0; j < D_IT; ++j) {
+        const int I = wid + j * NW;
+        if (D_INSTR % NW == 0 || I < D_INSTR)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(st + I * 1024), 16, vd[j],
+                                                   0, 0, 0);
+      }
+    }
+    if (c0 + 1 < c1) prep_chunk(c0 + 1);
+  }
+  unsigned long long pr_wait = 0, pr_bar = 0, pr_comp = 0, pr_iss = 0;
+#define WGW_NOW() (p.probe ? __builtin_readcyclecounter() : 0ull)
+  const unsigned long long pr_t0 = WGW_NOW();
+  for (int ci = c0; ci < c1; ++ci) {
+    const unsigned long long q0 = WGW_NOW();
+    wgw_wait_vmcnt<0>();
+    const unsigned long long q1 = WGW_NOW();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned long long q2 = WGW_NOW();
+    pr_wait += q1 - q0;
+    pr_bar += q2 - q1;
+    // next chunk: 64 new ring rows at the leading edge + its dy (both buffers were last read one barrier ago)
+    if (ci + 1 < c1) fire_chunk(ci + 1);
+    const unsigned long long q3 = WGW_NOW();
+    pr_iss += q3 - q2;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const uint32_t da = lds0 + XBYTES + (ci & 1) * DSTAGE;
+    // software-pipelined k-steps: wait for the fragments of step ks, put the reads of step ks+1 in flight, then the
+    // six MFMAs of step ks
+    s16x4 ra[2][2][2], rb[2][3][2];      // [buffer][tile][half]
+    auto issue_reads = [&](int buf, int ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t pa = da + a_rd[i] + ks * 16 * DROW;
+        ra[buf][i][0] = wgw_read_tr(pa);
+        ra[buf][i][1] = wgw_read_tr(pa + 4 * DROW);
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int d = (wr - 1) * p.Wp + (s - 1);
+        const int r0 = (ci * 64 + ks * 16 + rowl + d) & (RING - 1);
+        const int r1 = (r0 + 4) & (RING - 1);
+        const int lowb = ((wh ^ ((r0 >> 1) & 1)) << 6) + inseg;       // (r0 + 4) >> 1 has the parity of r0 >> 1
+        rb[buf][s][0] = wgw_read_tr(lds0 + r0 * 128 + lowb);
+        rb[buf][s][1] = wgw_read_tr(lds0 + r1 * 128 + lowb);
+      }
+    };
+    issue_reads(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1;
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(ra[cur][0][0]), "+v"(ra[cur][0][1]), "+v"(ra[cur][1][0]), "+v"(ra[cur][1][1]),
+                     "+v"(rb[cur][0][0]), "+v"(rb[cur][0][1]), "+v"(rb[cur][1][0]), "+v"(rb[cur][1][1]),
+                     "+v"(rb[cur][2][0]), "+v"(rb[cur][2][1])
+                   :
+                   : "memory");
+      if (ks < 3) issue_reads(cur ^ 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 af[2], bfr[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(ra[cur][i][0], ra[cur][i][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        bfr[s] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(rb[cur][s][0], rb[cur][s][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          acc[i][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[s], acc[i][s], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 1 && ci + 2 < c1) prep_chunk(ci + 2);      // address arithmetic underneath the MFMAs just issued
+    }
+    pr_comp += WGW_NOW() - q3;
+  }
+  if (p.probe && tid == 0) {
+    unsigned long long* o = p.probe + (size_t)blockIdx.x * 8;
+    o[0] = WGW_NOW() - pr_t0; o[1] = pr_wait; o[2] = pr_bar; o[3] = pr_iss; o[4] = pr_comp; o[5] = (unsigned long long)(c1 - c0);
+  }
+#undef WGW_NOW
+
+  if (p.dbg & 1) {      // timing experiment: no epilogue (one conditional store keeps the accumulators alive)
+    if (acc[0][0][0] + acc[1][2][5] == 12345.f) p.dw[0] = 1.f;
+    return;
+  }
+  // D[k (regs)][n (lanes)] -> fp32 atomics into [K][(r,s)][C]: 128 B contiguous per half-wave
+  const int ln = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int n = (wr * 3 + s) * p.C + cb * 64 + wh * 32 + ln;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = kt * 64 * KH + wk * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        atomicAdd(p.dw + (size_t)k * p.Ng + n, acc[i][s][e]);
+      }
+    }
+#endif   // __HIP_DEVICE_COMPILE__
+}
+
+static int g_wgw_on = 1;
+static int g_wgw_target = 512;
+static int g_wgw_dbg = 0;
+static unsigned long long* g_wgw_probe = nullptr;
+
+extern "C" {   // (internal to the library, except the two knobs: declared in conv_wgrad.hip / mpr_hip.h)
+
+int mpr_conv_set_wgrad_window(int on) {   // bits 8.. = timing-experiment flags (bit 8: skip the atomic epilogue)
+  const int old = g_wgw_on;
+  g_wgw_on = on & 255;
+  g_wgw_dbg = on >> 8;
+  return old;
+}
+
+int mpr_conv_debug_wgrad_probe(void* buf) {   // 8 x uint64 per workgroup of the next sliding-window wgrad launches
+  g_wgw_probe = (unsigned long long*)buf;
+  return 0;
+}
+
+bool mpr_wgw_eligible(long long Mpix, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
+                      long long min_pix) {
+  return g_wgw_on && R == 3 && S == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && C % 64 == 0 && K % 64 == 0 &&
+         W >= 2 && W <= 56 && H >= 2 && Mpix >= min_pix && (Mpix / (H * W)) * (long long)(H + 1) * (W + 1) < (1ll << 30);
+}
+
+// dw [K][3][3][C] += (zeroed by the caller unless accumulating) the weight gradient of x [B,H,W,C], dy [B,H,W,K]
+int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W, int C, int K, int target_wgs,
+                   hipStream_t st) {
+  WgwParams p;
+  p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw;
+  p.H = H; p.W = W; p.C = C; p.K = K;
+  p.Wp = W + 1; p.img = (H + 1) * (W + 1); p.Gtot = B * p.img; p.halo8 = (W + 2 + 7) / 8 * 8;
+  p.Ng = 9 * C; p.ncb = C / 64;
+  const int KH = K % 128 == 0 ? 2 : 1;
+  p.nkt = K / (64 * KH);
+  p.total_chunks = ceil_div(p.Gtot, 64);
+  const int tiles = p.ncb * p.nkt;
+  int nsplit = (target_wgs > 0 ? target_wgs : g_wgw_target) / tiles;
+  if (nsplit > ceil_div(p.total_chunks, 4)) nsplit = ceil_div(p.total_chunks, 4);
+  if (nsplit < 1) nsplit = 1;
+  p.cps = ceil_div(p.total_chunks, nsplit);
+  nsplit = ceil_div(p.total_chunks, p.cps);
+  p.x_bytes = (unsigned)((size_t)B * H * W * C * 2);
+  p.dy_bytes = (unsigned)((size_t)B * H * W * K * 2);
+  p.div_img = make_fastdiv(p.img); p.div_wp = make_fastdiv(p.Wp);
+  p.dbg = g_wgw_dbg;
+  p.probe = g_wgw_probe;
+  const dim3 grid(nsplit * tiles);
+  const size_t lds = 256 * 128 + 2 * 64 * 128 * (size_t)KH;
+  if (KH == 2) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    conv_wgrad_win_kernel<2><<<grid, 768, lds, st>>>(p);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    conv_wgrad_win_kernel<1><<<grid, 384, lds, st>>>(p);
+  }
+  MPR_LAUNCH_CHECK("conv_wgrad_win_kernel");
+  return MPR_OK;
+}
+
+}  // extern "C"

@@ -209,10 +209,62 @@ def conv_dgrad(dy, wd, g, x_shape, add=None):
     return dx
 
 
+AUTOTUNE = os.environ.get('MPR_AUTOTUNE', '1') != '0'
+_FIXED_WGRAD_WGS = int(os.environ.get('MPR_WGRAD_WGS', '0'))      # experiments: one target for every geometry
+_wgrad_split = {}          # geometry -> workgroup-count target of the split over pixels
+
+
+def _tune_wgrad(x, dy, g, key):
+    """First use of a large geometry: time the weight-gradient kernels -- the sliding-window kernel (3x3 stride 1 only)
+    and the gather kernel, each at a few workgroup-count targets of the split over pixels (occupancy rounds vs. atomic
+    traffic vs. L2 sharing differ shape by shape) -- on scratch output, and keep the fastest (window?, target)."""
+    B, H, W, C = _geom(x)
+    ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
+    win_ok = (g.R, g.S, g.sh, g.sw, g.ph, g.pw) == (3, 3, 1, 1, 1, 1)
+    cands = ([(1, 256), (1, 512)] if win_ok else []) + [(0, 256), (0, 512), (0, 768), (0, 1024)]
+    best, best_t = (0, 768), None
+    old_win = N.query('mpr_conv_set_wgrad_window', 1)
+    for win, tg in cands:
+        N.query('mpr_conv_set_wgrad_window', win)
+        N.query('mpr_conv_set_wgrad_target_wgs', tg)
+        N.call('mpr_conv_wgrad', x, dy, ws, None, 0, B, H, W, C, g.K, *g.tail)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            N.call('mpr_conv_wgrad', x, dy, ws, None, 1, B, H, W, C, g.K, *g.tail)
+        b.record()
+        b.synchronize()
+        t = a.elapsed_time(b)
+        if best_t is None or t < best_t:
+            best, best_t = (win, tg), t
+    N.query('mpr_conv_set_wgrad_window', old_win)
+    _wgrad_split[key] = best
+    return best
+
+
 def conv_wgrad(x, dy, g, weight):
     """Gradient of `weight` (a tensor: its layout and, if the optimizer installed one, its gradient memory are
     used; or a plain shape -> contiguous OIHW result).  Returns None when it accumulated into grad_target(weight)."""
     B, H, W, C = _geom(x)
+    restore_win = None
+    if _FIXED_WGRAD_WGS:
+        N.query('mpr_conv_set_wgrad_target_wgs', _FIXED_WGRAD_WGS)
+    elif AUTOTUNE and C % 64 == 0 and g.K % 64 == 0 and dy.numel() // g.K >= 16384:
+        key = (B, H, W, C, g.K, *g.tail)
+        choice = _wgrad_split.get(key)
+        if choice is None:
+            choice = _tune_wgrad(x, dy, g, key)
+        N.query('mpr_conv_set_wgrad_target_wgs', choice[1])
+        if not choice[0]:                       # the gather kernel won for this shape: window kernel off for this call
+            restore_win = N.query('mpr_conv_set_wgrad_window', 0)
+    try:
+        return _conv_wgrad(x, dy, g, weight, B, H, W, C)
+    finally:
+        if restore_win is not None:
+            N.query('mpr_conv_set_wgrad_window', restore_win)
+
+
+def _conv_wgrad(x, dy, g, weight, B, H, W, C):
     if not torch.is_tensor(weight):
         ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
         dw = torch.empty(weight, dtype=F32, device=x.device)

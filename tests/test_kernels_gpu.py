@@ -70,6 +70,8 @@ def igemm_path(request):
     thr = 1 << 30 if request.param == 'regs' else 0
     old_win = _native.query('mpr_conv_set_window', 1 if request.param == 'win' else 0)
     request.addfinalizer(lambda: _native.query('mpr_conv_set_window', old_win))
+    old_ww = _native.query('mpr_conv_set_wgrad_window', 1 if request.param == 'win' else 0)
+    request.addfinalizer(lambda: _native.query('mpr_conv_set_wgrad_window', old_ww))
     old = _native.query('mpr_conv_set_dma_min_rows', thr)
     old_w = _native.query('mpr_conv_set_wgrad_dma_min_pixels', thr)
     old_p = _native.query('mpr_conv_set_dgrad_parity', 2)      # parity classes for 1x1 filters too
