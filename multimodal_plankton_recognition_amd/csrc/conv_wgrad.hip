@@ -189,6 +189,11 @@ template <int N>
 __device__ __forceinline__ void wg_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+__device__ __forceinline__ s16x4 wg_read_tr(uint32_t lds_addr) {   // ds_read_b64_tr_b16 the compiler cannot see
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+  return v;
+}
 template <int CH>   // 64-B segment swizzle for unpadded rows of CH 16-B chunks (row strides 128 / 256 / 384 B)
 __device__ __forceinline__ int wg_seg_xor(int row) {
   return CH == 16 ? (row & 3) : ((row >> 1) & 1);
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = BKP * BSTR / 1024;
   constexpr int A_IT = (A_INSTR + NW - 1) / NW, B_IT = (B_INSTR + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -345,27 +351,34 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
       issue_chunk(ci + 1);
       decode_chunk(ci + 2);
     }
-    const unsigned char* a = smem + (ci & 1) * STAGE;
-    // software-pipelined k-steps (as conv_igemm.hip): the transposing reads of step ks+1 are in flight, in their own
-    // registers, while the four MFMAs of step ks run
-    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    const uint32_t a = lds0 + (ci & 1) * STAGE;
+    // software-pipelined k-steps: wait for the fragments of step ks, put the transposing reads of step ks+1 in flight
+    // (their own registers), then the four MFMAs of step ks.  The reads are INLINE ASM: through the builtin hipcc
+    // cannot tell them from the LDS-DMA writes in flight and puts s_waitcnt vmcnt(0) in front -- every chunk would wait
+    // for the next chunk's DMA it has just issued.  Completion is by hand: the s_waitcnt lgkmcnt(0) below carries the
+    // destination registers as in/out operands, so every consumer is ordered behind it.
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x4 ra[2][2][2], rb[2][2][2];      // [buffer][tile][half]
     auto load_frags = [&](int buf, int ks) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const unsigned char* pa = a + a_rd[t] + ks * 16 * ASTR;
-        const unsigned char* pb = a + b_rd[t] + ks * 16 * BSTR;
-        ra[buf][t][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa));
-        ra[buf][t][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + 4 * ASTR));
-        rb[buf][t][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb));
-        rb[buf][t][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb + 4 * BSTR));
+        const uint32_t pa = a + a_rd[t] + ks * 16 * ASTR;
+        const uint32_t pb = a + b_rd[t] + ks * 16 * BSTR;
+        ra[buf][t][0] = wg_read_tr(pa);
+        ra[buf][t][1] = wg_read_tr(pa + 4 * ASTR);
+        rb[buf][t][0] = wg_read_tr(pb);
+        rb[buf][t][1] = wg_read_tr(pb + 4 * BSTR);
       }
     };
     load_frags(0, 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = ks & 1;
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(ra[cur][0][0]), "+v"(ra[cur][0][1]), "+v"(ra[cur][1][0]), "+v"(ra[cur][1][1]),
+                     "+v"(rb[cur][0][0]), "+v"(rb[cur][0][1]), "+v"(rb[cur][1][0]), "+v"(rb[cur][1][1])
+                   :
+                   : "memory");
       if (ks < 3) load_frags(cur ^ 1, ks + 1);
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 af[2], bfr[2];
