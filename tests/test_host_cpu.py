@@ -77,7 +77,8 @@ def test_transforms_follow_reference_ranges(tmp_path):
     assert a.shape == x.shape and b.shape == p.shape
 
 
-@pytest.mark.parametrize('card', ['resnet18_cnn_2_512_clip.yaml', 'example_multi.yaml', 'smoke_multi.yaml'])
+@pytest.mark.parametrize('card', ['resnet18_cnn_2_512_clip.yaml', 'example_multi.yaml', 'smoke_multi.yaml',
+                                  'vit_base_transformer_siglip.yaml'])
 def test_model_cards_follow_the_schema_the_script_reads(card):
     from multimodal_plankton_recognition_amd.model import MultiModel
     c = yaml.safe_load(open(os.path.join(ROOT, 'model_cards', card)))
@@ -88,3 +89,15 @@ def test_model_cards_follow_the_schema_the_script_reads(card):
     assert m.image_projection.weight.shape[0] == c['dim_embedding']
     assert set(m.hparams) == {'dim_embed', 'image_encoder_args', 'profile_encoder_args', 'coordination_args',
                               'optim_args'}
+
+
+def test_single_modality_cards_build_their_models():
+    """BASELINE configs C1 / C2: the model half of the (out-of-scope) single-modality scripts."""
+    from multimodal_plankton_recognition_amd.model import ImageModel, ProfileModel
+    names = [f'class{i}' for i in range(7)]
+    c1 = yaml.safe_load(open(os.path.join(ROOT, 'model_cards', 'example_profile.yaml')))
+    pm = ProfileModel(c1['profile_encoder_args'], c1['optim_args'], names)
+    assert type(pm.profile_encoder).__name__ == 'ProfileTransformer'
+    c2 = yaml.safe_load(open(os.path.join(ROOT, 'model_cards', 'example_image.yaml')))
+    im = ImageModel(c2['image_encoder_args'], c2['optim_args'], names)
+    assert im.image_encoder.dim_out == 512 + 2
