@@ -125,6 +125,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    local_rank %= torch.cuda.device_count()          # (rehearsals put several ranks on one GPU: MPR_DIST_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 

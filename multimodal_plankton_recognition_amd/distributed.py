@@ -33,6 +33,8 @@ def init(device=None, backend=None):
     if dist.is_initialized():
         return
     if backend is None:
+        backend = os.environ.get('MPR_DIST_BACKEND')       # 'gloo': rehearsal of the N > 1 path on a box with fewer GPUs
+    if backend is None:
         backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
@@ -67,14 +69,27 @@ class Comm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
+    def _staged(self, x):
+        # gloo rehearsal with device tensors (several ranks sharing one GPU): stage through the host
+        return x.is_cuda and dist.get_backend(self.group) == 'gloo'
+
     def all_gather(self, x):
         """[...] -> [world, ...] (rank-major)."""
         x = x.contiguous()
+        if self._staged(x):
+            out = torch.empty(self.world * x.numel(), dtype=x.dtype)
+            dist.all_gather_into_tensor(out, x.reshape(-1).cpu(), group=self.group)
+            return out.to(x.device).view((self.world,) + tuple(x.shape))
         out = torch.empty(self.world * x.numel(), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x.reshape(-1), group=self.group)
         return out.view((self.world,) + tuple(x.shape))
 
     def all_reduce_sum(self, x):
+        if self._staged(x):
+            h = x.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            x.copy_(h)
+            return x
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x
 
