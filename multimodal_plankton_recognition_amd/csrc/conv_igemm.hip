@@ -585,6 +585,7 @@ struct PackEntry {            // 12 x int64: one row of the table of mpr_conv_pa
   long long K, C, R, S, sk, sc, sr, ss, pad_;
 };
 
+template <bool TILED_WD>
 __device__ __forceinline__ void pack_one(const PackEntry& e, int first, int step) {
   const int K = (int)e.K, C = (int)e.C, R = (int)e.R, S = (int)e.S;
   const int KgF = R * S * C, KgD = R * S * K;
@@ -599,7 +600,7 @@ __device__ __forceinline__ void pack_one(const PackEntry& e, int first, int step
         v = e.w[k * e.sk + c * e.sc + r * e.sr + s * e.ss];
       }
       e.wf[i] = (bf16_t)v;
-    } else {
+    } else if (!TILED_WD) {
       const int j = i - totalF;
       const int c = j / KgDpad, g = j - c * KgDpad;
       float v = 0.f;
@@ -608,17 +609,51 @@ __device__ __forceinline__ void pack_one(const PackEntry& e, int first, int step
         v = e.w[k * e.sk + c * e.sc + r * e.sr + s * e.ss];
       }
       e.wd[j] = (bf16_t)v;
+    } else {
+      // tiled variant: only the zero padding of the data-gradient panel here, its body below
+      const int j = i - totalF;
+      const int c = j / KgDpad, g = j - c * KgDpad;
+      if (c >= C || g >= KgD) e.wd[j] = (bf16_t)0.f;
+    }
+  }
+}
+
+// Data-gradient panel wd[c][(tap, k)] = w[k][tap][c]: a K x C transpose per tap.  Read straight through, one side of it
+// is a 4-byte access every K (or R*S*C) elements -- 577 MB of traffic for 45 MB of filters; through a 32 x 33 LDS tile
+// both sides are contiguous.  Whole 256-thread workgroup per tile, tiles strided over gridDim.x.
+__device__ __forceinline__ void pack_wd_tiled(const PackEntry& e) {
+  __shared__ float tile[32][33];
+  const int K = (int)e.K, C = (int)e.C, taps = (int)(e.R * e.S), S = (int)e.S;
+  const int KgDpad = (taps * K + 63) / 64 * 64;
+  const int tk = (K + 31) / 32, tc = (C + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  for (int t = blockIdx.x; t < taps * tk * tc; t += gridDim.x) {
+    const int tap = t / (tk * tc), rem = t - tap * (tk * tc);
+    const int k0 = (rem / tc) * 32, c0 = (rem % tc) * 32;
+    const int r = tap / S, s = tap - r * S;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int k = k0 + ty + 8 * p, c = c0 + tx;
+      tile[ty + 8 * p][tx] = (k < K && c < C) ? e.w[k * e.sk + c * e.sc + r * e.sr + s * e.ss] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int c = c0 + ty + 8 * p, k = k0 + tx;
+      if (c < C && k < K) e.wd[(size_t)c * KgDpad + tap * K + k] = (bf16_t)tile[tx][ty + 8 * p];
     }
   }
 }
 
 __global__ void conv_pack_weights_kernel(const PackEntry e) {
-  pack_one(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  pack_one<false>(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
-__global__ void conv_pack_weights_multi_kernel(const PackEntry* __restrict__ table) {
+__global__ __launch_bounds__(256) void conv_pack_weights_multi_kernel(const PackEntry* __restrict__ table) {
   const PackEntry e = table[blockIdx.y];
-  pack_one(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  pack_one<true>(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  if (e.wd) pack_wd_tiled(e);
 }
 
 static inline int pad_to(int x, int a) { return (x + a - 1) / a * a; }

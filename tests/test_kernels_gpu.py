@@ -335,3 +335,23 @@ def test_fused_sgd_matches_torch():
         o_mine.step()
     for a, b in zip(ref, mine):
         np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 3, 3), (24, 40, 3, 3), (128, 64, 1, 1), (72, 8, 4, 4)])
+def test_multi_tensor_weight_pack_equals_single_pack(shape):
+    """The one-launch repack of every filter panel (tiled transpose for the data-gradient panel) must reproduce the
+    single-filter pack bit for bit, for OIHW and for channels-last ([K][R][S][C]) weight memory."""
+    ops = _ops()
+    from multimodal_plankton_recognition_amd import _native as N
+    K, C, R, S = shape
+    g = ops.ConvGeom(shape, 1, R // 2)
+    for krsc in (False, True):
+        w = rnd(*shape, seed=5).to(DEV)
+        if krsc:
+            w = w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        wf, wd = ops.packed_weights(w, g)
+        wf_ref, wd_ref = wf.clone(), wd.clone()
+        wf.fill_(7.0)
+        wd.fill_(7.0)
+        ops.pack_registry.repack_all()
+        assert torch.equal(wf, wf_ref) and torch.equal(wd, wd_ref), (shape, krsc)
