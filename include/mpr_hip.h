@@ -87,6 +87,10 @@ int mpr_conv_set_wgrad_target_wgs(int n);
 /* weight gradients of 3x3 / stride 1 / pad 1 convolutions (C, K multiples of 64) run on the sliding-window kernel
  * (conv_wgrad_win.hip); 0 switches it off (tests / comparisons); returns the previous setting */
 int mpr_conv_set_wgrad_window(int on);
+/* lend `floats` floats of device scratch to the NEXT mpr_conv_wgrad call (one-shot): the sliding-window kernel then
+ * writes each pixel split's partial tile with plain stores and sums the slices in a second kernel on the same stream,
+ * instead of fp32 atomics (75 MB per launch at the chip's ~1.3 TB/s atomic rate); too small / NULL: atomics */
+int mpr_conv_set_wgrad_scratch(void* buf, long long floats);
 int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may be NULL */, int B, int H, int W,
                  int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
 int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add /* may be NULL */, int B, int H,

@@ -448,7 +448,8 @@ extern "C" {
 bool mpr_wgw_eligible(long long Mpix, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
                       long long min_pix);
 int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W, int C, int K, int target_wgs,
-                   hipStream_t st);
+                   float* scratch, long long scratch_floats, hipStream_t st);
+void mpr_wgw_take_scratch(float** buf, long long* floats);
 
 int mpr_conv_set_wgrad_dma_min_pixels(int pixels) {   // tuning / test knob; returns the previous value
   const int old = g_wgrad_dma_min_pix;
@@ -467,6 +468,9 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   MPR_REQUIRE((long long)B * H * W * C < (1ll << 31) && (long long)B * P * Q * K < (1ll << 31),
               "mpr_conv_wgrad: tensor exceeds 2^31 elements");
   hipStream_t st = (hipStream_t)stream;
+  float* scratch = nullptr;
+  long long scratch_floats = 0;
+  mpr_wgw_take_scratch(&scratch, &scratch_floats);       // one-shot loan for this call (conv_wgrad_win.hip)
   WgradParams p;
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = workspace;
   p.H = H; p.W = W; p.C = C; p.K = K; p.P = P; p.Q = Q; p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
@@ -485,7 +489,7 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
     // 3x3 / stride 1 / pad 1: sliding-window kernel (conv_wgrad_win.hip)
     void* tok = mpr_prof_begin(2, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
     mpr_prof_bytes(tok, (double)p.x_bytes + (double)p.dy_bytes + 4.0 * K * p.Ng);
-    const int rc = mpr_wgw_launch(x, dy, workspace, B, H, W, C, K, g_wgrad_target_wgs, st);
+    const int rc = mpr_wgw_launch(x, dy, workspace, B, H, W, C, K, g_wgrad_target_wgs, scratch, scratch_floats, st);
     mpr_prof_end(tok, st);
     if (rc != MPR_OK) return rc;
     if (dw_oihw) {

@@ -21,6 +21,7 @@ struct WgwParams {
   const bf16_t* x;     // [B,H,W,C]
   const bf16_t* dy;    // [B,H,W,K]
   float* dw;           // [K][9*C]
+  float* part;         // partial slices [nsplit][K][9*C] (plain stores + reduction pass) or NULL (atomics into dw)
   int H, W, C, K;
   int Wp, img, Gtot, halo8;   // W+1, (H+1)*(W+1), B*img, (W+2) rounded up to 8
   int Ng, ncb, nkt, cps, total_chunks;
@@ -266,8 +267,11 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
     if (acc[0][0][0] + acc[1][2][5] == 12345.f) p.dw[0] = 1.f;
     return;
   }
-  // D[k (regs)][n (lanes)] -> fp32 atomics into [K][(r,s)][C]: 128 B contiguous per half-wave
+  // D[k (regs)][n (lanes)], 128 B contiguous per half-wave: plain stores into this pixel split's slice (summed by
+  // wgw_reduce_kernel) when the caller lent scratch memory -- the chip adds ~1.3 TB/s of fp32 atomics but stores
+  // ~6 TB/s, and every launch emits 256 CUs x 295 KB of accumulators -- else fp32 atomics into [K][(r,s)][C]
   const int ln = lane & 31, lh = lane >> 5;
+  float* const slice = p.part ? p.part + (size_t)split * p.K * p.Ng : nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -276,18 +280,47 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int k = kt * 64 * KH + wk * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        atomicAdd(p.dw + (size_t)k * p.Ng + n, acc[i][s][e]);
+        if (slice) slice[(size_t)k * p.Ng + n] = acc[i][s][e];
+        else atomicAdd(p.dw + (size_t)k * p.Ng + n, acc[i][s][e]);
       }
     }
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
+// dw[i] += sum over the pixel splits of part[s][i]   (float4 per thread; the slices are L2 / Infinity-Cache warm)
+__global__ __launch_bounds__(256) void wgw_reduce_kernel(const float4* __restrict__ part, int nsplit, float4* __restrict__ dw,
+                                                          int n4) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    float4 a = dw[i];
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+      const float4 v0 = part[(size_t)s * n4 + i], v1 = part[(size_t)(s + 1) * n4 + i];
+      const float4 v2 = part[(size_t)(s + 2) * n4 + i], v3 = part[(size_t)(s + 3) * n4 + i];
+      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < nsplit; ++s) {
+      const float4 v = part[(size_t)s * n4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    dw[i] = a;
+  }
+}
+
 static int g_wgw_on = 1;
+static float* g_wgw_scratch = nullptr;        // lent by the caller for the NEXT launch (mpr_conv_set_wgrad_scratch)
+static long long g_wgw_scratch_floats = 0;
 static int g_wgw_target = 512;
 static int g_wgw_dbg = 0;
 static unsigned long long* g_wgw_probe = nullptr;
 
 extern "C" {   // (internal to the library, except the two knobs: declared in conv_wgrad.hip / mpr_hip.h)
+
+int mpr_conv_set_wgrad_scratch(void* buf, long long floats) {
+  g_wgw_scratch = (float*)buf;
+  g_wgw_scratch_floats = buf ? floats : 0;
+  return 0;
+}
 
 int mpr_conv_set_wgrad_window(int on) {   // bits 8.. = timing-experiment flags (bit 8: skip the atomic epilogue)
   const int old = g_wgw_on;
@@ -308,8 +341,16 @@ bool mpr_wgw_eligible(long long Mpix, int H, int W, int C, int K, int R, int S, 
 }
 
 // dw [K][3][3][C] += (zeroed by the caller unless accumulating) the weight gradient of x [B,H,W,C], dy [B,H,W,K]
+// one-shot scratch of mpr_conv_set_wgrad_scratch: read and cleared by EVERY mpr_conv_wgrad call, whichever kernel it takes
+void mpr_wgw_take_scratch(float** buf, long long* floats) {
+  *buf = g_wgw_scratch;
+  *floats = g_wgw_scratch_floats;
+  g_wgw_scratch = nullptr;
+  g_wgw_scratch_floats = 0;
+}
+
 int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W, int C, int K, int target_wgs,
-                   hipStream_t st) {
+                   float* scratch, long long scratch_floats, hipStream_t st) {
   WgwParams p;
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw;
   p.H = H; p.W = W; p.C = C; p.K = K;
@@ -329,6 +370,8 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   p.div_img = make_fastdiv(p.img); p.div_wp = make_fastdiv(p.Wp);
   p.dbg = g_wgw_dbg;
   p.probe = g_wgw_probe;
+  // partial slices instead of atomics when the caller lent enough scratch for THIS launch (one-shot)
+  p.part = (scratch && (long long)nsplit * K * p.Ng <= scratch_floats) ? scratch : nullptr;
   const dim3 grid(nsplit * tiles);
   const size_t lds = 256 * 128 + 2 * 64 * 128 * (size_t)KH;
   if (KH == 2) {
@@ -347,6 +390,12 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
     conv_wgrad_win_kernel<1><<<grid, 384, lds, st>>>(p);
   }
   MPR_LAUNCH_CHECK("conv_wgrad_win_kernel");
+  if (p.part) {
+    const int n4 = K * p.Ng / 4;
+    wgw_reduce_kernel<<<ceil_div(n4, 256) < 1024 ? ceil_div(n4, 256) : 1024, 256, 0, st>>>((const float4*)p.part, nsplit,
+                                                                                          (float4*)dw, n4);
+    MPR_LAUNCH_CHECK("wgw_reduce_kernel");
+  }
   return MPR_OK;
 }
 

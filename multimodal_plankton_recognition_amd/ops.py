@@ -214,6 +214,26 @@ _FIXED_WGRAD_WGS = int(os.environ.get('MPR_WGRAD_WGS', '0'))      # experiments:
 _wgrad_split = {}          # geometry -> workgroup-count target of the split over pixels
 
 
+WGRAD_SCRATCH_FLOATS = 20 * 1024 * 1024      # 80 MB per stream: 256 workgroups x 128 x 576 accumulators (+ margin)
+_wgrad_scratch = {}                          # raw stream handle -> scratch tensor
+
+
+def _wgrad_call(x, dy, out, dw, accumulate, B, H, W, C, K, R, S, sh, sw, ph, pw, stream_handle=None):
+    """mpr_conv_wgrad, lending the sliding-window kernel per-stream scratch for its partial tiles (plain stores + one
+    reduction pass instead of 75 MB of fp32 atomics per launch).  The loan is one-shot: consecutive launches on one
+    stream reuse the buffer in stream order, launches on different streams have different buffers."""
+    if (R, S, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and C % 64 == 0 and K % 64 == 0 and USE_WGRAD_SCRATCH:
+        h = stream_handle if stream_handle is not None else N.stream(x.device.index)
+        buf = _wgrad_scratch.get(h)
+        if buf is None:
+            buf = _wgrad_scratch[h] = torch.empty(WGRAD_SCRATCH_FLOATS, dtype=F32, device=x.device)
+        N.query('mpr_conv_set_wgrad_scratch', buf.data_ptr(), buf.numel())
+    N.call('mpr_conv_wgrad', x, dy, out, dw, accumulate, B, H, W, C, K, R, S, sh, sw, ph, pw, stream_handle=stream_handle)
+
+
+USE_WGRAD_SCRATCH = os.environ.get('MPR_WGRAD_SCRATCH', '1') != '0'
+
+
 def _tune_wgrad(x, dy, g, key):
     """First use of a large geometry: time the weight-gradient kernels -- the sliding-window kernel (3x3 stride 1 only)
     and the gather kernel, each at a few workgroup-count targets of the split over pixels (occupancy rounds vs. atomic
@@ -227,11 +247,11 @@ def _tune_wgrad(x, dy, g, key):
     for win, tg in cands:
         N.query('mpr_conv_set_wgrad_window', win)
         N.query('mpr_conv_set_wgrad_target_wgs', tg)
-        N.call('mpr_conv_wgrad', x, dy, ws, None, 0, B, H, W, C, g.K, *g.tail)
+        _wgrad_call(x, dy, ws, None, 0, B, H, W, C, g.K, *g.tail)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(3):
-            N.call('mpr_conv_wgrad', x, dy, ws, None, 1, B, H, W, C, g.K, *g.tail)
+            _wgrad_call(x, dy, ws, None, 1, B, H, W, C, g.K, *g.tail)
         b.record()
         b.synchronize()
         t = a.elapsed_time(b)
@@ -268,7 +288,7 @@ def _conv_wgrad(x, dy, g, weight, B, H, W, C):
     if not torch.is_tensor(weight):
         ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
         dw = torch.empty(weight, dtype=F32, device=x.device)
-        N.call('mpr_conv_wgrad', x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail)
+        _wgrad_call(x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail)
         return dw
     tgt = grad_target(weight)
     if is_krsc(weight):          # the kernel's native [K][R][S][C] result IS the gradient's memory
@@ -276,22 +296,22 @@ def _conv_wgrad(x, dy, g, weight, B, H, W, C):
             if ASYNC_WGRAD:
                 cur, side = _wgrad_stream(x.device.index)
                 side.wait_stream(cur)
-                N.call('mpr_conv_wgrad', x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail, stream_handle=side.cuda_stream)
+                _wgrad_call(x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail, stream_handle=side.cuda_stream)
                 x.record_stream(side)           # the allocator must not recycle the operands under the side stream
                 dy.record_stream(side)
                 _note_arena_stream(x.device.index, side)
             else:
-                N.call('mpr_conv_wgrad', x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail)
+                _wgrad_call(x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail)
             return None
         dw = torch.empty_strided(weight.shape, weight.stride(), dtype=F32, device=x.device)
-        N.call('mpr_conv_wgrad', x, dy, dw, None, 0, B, H, W, C, g.K, *g.tail)
+        _wgrad_call(x, dy, dw, None, 0, B, H, W, C, g.K, *g.tail)
         return dw
     ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
     if tgt is not None and tgt.is_contiguous():
-        N.call('mpr_conv_wgrad', x, dy, ws, tgt, 1, B, H, W, C, g.K, *g.tail)
+        _wgrad_call(x, dy, ws, tgt, 1, B, H, W, C, g.K, *g.tail)
         return None
     dw = torch.empty(weight.shape, dtype=F32, device=x.device)
-    N.call('mpr_conv_wgrad', x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail)
+    _wgrad_call(x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail)
     return dw
 
 
