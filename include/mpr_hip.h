@@ -134,6 +134,17 @@ int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float*
 int mpr_bn_bwd_finalize(const float* partials, int nparts, long long count, const float* gamma, const float* mean,
                         const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef /* [3][C] */,
                         int C, void* stream);
+/* mpr_bn_reduce_partials + mpr_bn_finalize_stats / mpr_bn_bwd_finalize in ONE launch: every workgroup writes its
+ * slice row of `slices` [nsplit][2][C], the last one (device-side ticket) sums the slices and finalizes.
+ * `ticket`: one int of device memory, zero on entry; the kernel leaves it zero again. */
+int mpr_bn_reduce_finalize_stats(const float* partials, int nparts, float* slices, int nsplit, int* ticket,
+                                 long long count, const float* gamma, const float* beta,
+                                 float* running_mean /* may be NULL */, float* running_var, float momentum, float eps,
+                                 float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
+int mpr_bn_reduce_bwd_finalize(const float* partials, int nparts, float* slices, int nsplit, int* ticket,
+                               long long count, const float* gamma, const float* mean, const float* invstd,
+                               float* dgamma, float* dbeta, int accumulate, float* coef /* [3][C] */, int C,
+                               void* stream);
 int mpr_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coef, const float* scale,
                      const float* shift, int mask_mode, void* dx, void* dz_out /* may be NULL */, long long rows,
                      int C, void* stream);

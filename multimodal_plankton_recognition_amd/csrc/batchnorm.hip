@@ -74,6 +74,83 @@ __global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __
   }
 }
 
+// The same pre-reduction with the finalize step folded in ("last workgroup finishes the job"): every workgroup writes
+// its slice row, releases it (agent-scope fence) and takes a ticket; the workgroup that draws the last ticket acquires,
+// sums the nsplit slice rows per channel (double) and computes the per-channel coefficients -- one launch where there
+// were two.  These 5-us launches sit in the dependent chain of every BatchNorm, forward and backward (80 per step), and
+// under the concurrent weight-gradient stream each one queues for 10-30 us.
+//   MODE 0 (forward):  scale / shift / mean / invstd (+ running statistics)      MODE 1 (backward): dgamma / dbeta / coef
+// `ticket` is one int, zero on entry and reset to zero by the last workgroup.
+struct BnFinalizeArgs {
+  float count, momentum, eps;
+  const float *gamma, *beta, *mean_in, *invstd_in;
+  float *running_mean, *running_var, *scale, *shift, *mean_out, *invstd_out;   // MODE 0
+  float *dgamma, *dbeta, *coef;                                                // MODE 1
+  int accumulate;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* __restrict__ partials, int nparts,
+                                                                 float* __restrict__ out, int nsplit, int C,
+                                                                 int* __restrict__ ticket, const BnFinalizeArgs a) {
+  const int C2 = 2 * C;
+  __shared__ double red[8][33];
+  __shared__ int last;
+  {
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5, s = blockIdx.y;
+    double v = 0.0;
+    if (c < C2)
+      for (int i = s + pl * nsplit; i < nparts; i += 8 * nsplit) v += (double)partials[(size_t)i * C2 + c];
+    red[pl][threadIdx.x & 31] = v;
+    __syncthreads();
+    if (pl == 0 && c < C2) {
+      for (int i = 1; i < 8; ++i) v += red[i][threadIdx.x];
+      out[(size_t)s * C2 + c] = (float)v;
+    }
+  }
+  __threadfence();                       // release this workgroup's slice row (agent scope)
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(ticket, 1) == (int)(gridDim.x * gridDim.y) - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();                       // acquire the other workgroups' rows
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < nsplit; ++s) {
+      s1 += (double)__builtin_nontemporal_load(out + (size_t)s * C2 + c);
+      s2 += (double)__builtin_nontemporal_load(out + (size_t)s * C2 + C + c);
+    }
+    if (MODE == 0) {
+      const double mean = s1 / a.count;
+      double var = s2 / a.count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+      const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+      a.scale[c] = g * invstd;
+      a.shift[c] = b - (float)mean * g * invstd;
+      a.mean_out[c] = (float)mean;
+      a.invstd_out[c] = invstd;
+      if (a.running_mean) {
+        const double unbiased = a.count > 1.f ? var * (double)a.count / ((double)a.count - 1.0) : var;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+      }
+    } else {
+      const float sum_dz = (float)s1, sum_dzx = (float)s2;
+      const float g = a.gamma ? a.gamma[c] : 1.f, is = a.invstd_in[c], mu = a.mean_in[c];
+      if (a.dgamma) a.dgamma[c] = a.accumulate ? a.dgamma[c] + sum_dzx : sum_dzx;
+      if (a.dbeta) a.dbeta[c] = a.accumulate ? a.dbeta[c] + sum_dz : sum_dz;
+      const float k1 = g * is;
+      const float k2 = -g * is * is * sum_dzx / a.count;
+      const float k3 = -g * is * sum_dz / a.count - k2 * mu;
+      a.coef[c] = k1;
+      a.coef[C + c] = k2;
+      a.coef[2 * C + c] = k3;
+    }
+  }
+  if (threadIdx.x == 0) *ticket = 0;     // ready for the next use of this slot
+}
+
 // eval-mode coefficients from the running statistics
 __global__ void bn_eval_coefs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
@@ -310,6 +387,40 @@ int mpr_bn_finalize_stats(const float* partials, int nparts, long long count, co
       partials, nparts, (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean,
       invstd, C);
   MPR_LAUNCH_CHECK("bn_finalize_stats_kernel");
+  return MPR_OK;
+}
+
+// mpr_bn_reduce_partials + mpr_bn_finalize_stats in ONE launch (the last workgroup finalizes).
+// slices: scratch [nsplit][2][C] floats; ticket: one int, zero on entry (the kernel leaves it zero again).
+int mpr_bn_reduce_finalize_stats(const float* partials, int nparts, float* slices, int nsplit, int* ticket,
+                                 long long count, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                                 float* invstd, int C, void* stream) {
+  MPR_REQUIRE(partials && slices && ticket && scale && shift && mean && invstd && nsplit > 0 && nsplit <= nparts,
+              "mpr_bn_reduce_finalize_stats: bad arguments");
+  BnFinalizeArgs a = {};
+  a.count = (float)count; a.momentum = momentum; a.eps = eps;
+  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.scale = scale; a.shift = shift; a.mean_out = mean; a.invstd_out = invstd;
+  bn_reduce_finalize_kernel<0><<<dim3(ceil_div(2 * C, 32), nsplit), 256, 0, (hipStream_t)stream>>>(
+      partials, nparts, slices, nsplit, C, ticket, a);
+  MPR_LAUNCH_CHECK("bn_reduce_finalize_kernel<0>");
+  return MPR_OK;
+}
+
+// mpr_bn_reduce_partials + mpr_bn_bwd_finalize in ONE launch.
+int mpr_bn_reduce_bwd_finalize(const float* partials, int nparts, float* slices, int nsplit, int* ticket,
+                               long long count, const float* gamma, const float* mean, const float* invstd,
+                               float* dgamma, float* dbeta, int accumulate, float* coef, int C, void* stream) {
+  MPR_REQUIRE(partials && slices && ticket && mean && invstd && coef && nsplit > 0 && nsplit <= nparts,
+              "mpr_bn_reduce_bwd_finalize: bad arguments");
+  BnFinalizeArgs a = {};
+  a.count = (float)count;
+  a.gamma = gamma; a.mean_in = mean; a.invstd_in = invstd;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.coef = coef; a.accumulate = accumulate;
+  bn_reduce_finalize_kernel<1><<<dim3(ceil_div(2 * C, 32), nsplit), 256, 0, (hipStream_t)stream>>>(
+      partials, nparts, slices, nsplit, C, ticket, a);
+  MPR_LAUNCH_CHECK("bn_reduce_finalize_kernel<1>");
   return MPR_OK;
 }
 

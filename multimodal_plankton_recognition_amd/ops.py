@@ -373,6 +373,23 @@ def stem_wgrad(x, dy, g, weight):
 
 
 # ------------------------------------------------------------------------------------------ batch norm
+_ticket_pool = {}
+# Measured WORSE and therefore off: the last-workgroup pattern needs agent-scope release/acquire fences, and a release
+# fence writes back the XCD's whole dirty L2 -- which at that point holds the conv output just produced (15.3 vs 12.9 ms
+# per C3 step).  Kept as an option for the record.
+FUSED_FINALIZE = os.environ.get('MPR_FUSED_FINALIZE', '0') != '0'
+
+
+def _ticket(dev):
+    """One zeroed int of device memory for a last-workgroup-finishes kernel (it leaves the int zero again).  Slots
+    rotate through a pool so that launches in flight on different streams never share one."""
+    pool = _ticket_pool.get(dev)
+    if pool is None:
+        pool = _ticket_pool[dev] = [torch.zeros(4096, dtype=torch.int32, device=dev), 0]
+    pool[1] = (pool[1] + 1) % 4096
+    return pool[0][pool[1]:pool[1] + 1]
+
+
 def _prereduce(parts):
     """Long per-workgroup partial lists are folded to 64 rows first (spreads the read over the chip)."""
     n, _, C = parts.shape
@@ -402,10 +419,17 @@ def bn_coefs(stats, count, bn, train, x=None):
             N.call('mpr_bn_stats', x, stats, rows, C)
         st.mean = torch.empty(C, dtype=F32, device=dev)
         st.invstd = torch.empty(C, dtype=F32, device=dev)
-        stats = _prereduce(stats)
-        N.call('mpr_bn_finalize_stats', stats, stats.shape[0], count, bn.weight.detach(), bn.bias.detach(),
-               bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps), st.scale, st.shift,
-               st.mean, st.invstd, C)
+        if FUSED_FINALIZE and stats.shape[0] > 512:
+            # long partial list: pre-reduction and finalize in one launch (the last workgroup finalizes)
+            slices = torch.empty(64, 2, C, dtype=F32, device=dev)
+            N.call('mpr_bn_reduce_finalize_stats', stats, stats.shape[0], slices, 64, _ticket(dev), count,
+                   bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, float(bn.momentum),
+                   float(bn.eps), st.scale, st.shift, st.mean, st.invstd, C)
+        else:
+            stats = _prereduce(stats)
+            N.call('mpr_bn_finalize_stats', stats, stats.shape[0], count, bn.weight.detach(), bn.bias.detach(),
+                   bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps), st.scale, st.shift,
+                   st.mean, st.invstd, C)
     else:
         st.mean = st.invstd = None
         N.call('mpr_bn_eval_coefs', bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
@@ -431,6 +455,17 @@ def _bn_grad_targets(gamma, beta, C, dev):
     return torch.empty(C, dtype=F32, device=dev), torch.empty(C, dtype=F32, device=dev), 0, True
 
 
+def _bwd_finalize(parts, rows, gamma, st, dgamma, dbeta, acc, coef, C, dev):
+    if FUSED_FINALIZE and parts.shape[0] > 512:
+        slices = torch.empty(64, 2, C, dtype=F32, device=dev)
+        N.call('mpr_bn_reduce_bwd_finalize', parts, parts.shape[0], slices, 64, _ticket(dev), rows, gamma.detach(),
+               st.mean, st.invstd, dgamma, dbeta, acc, coef, C)
+    else:
+        parts = _prereduce(parts)
+        N.call('mpr_bn_bwd_finalize', parts, parts.shape[0], rows, gamma.detach(), st.mean, st.invstd, dgamma, dbeta,
+               acc, coef, C)
+
+
 def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False, beta=None):
     """-> dx (bf16), dgamma, dbeta (fp32; None when accumulated into the optimizer's buffers), dz (bf16 | None)."""
     C = x.shape[-1]
@@ -438,11 +473,9 @@ def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False, beta=None):
     dev = x.device
     parts = torch.empty(N.query('mpr_bn_reduce_rows', rows, C), 2, C, dtype=F32, device=dev)
     N.call('mpr_bn_bwd_reduce', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, rows, C)
-    parts = _prereduce(parts)
     dgamma, dbeta, acc, ret = _bn_grad_targets(gamma, beta, C, dev)
     coef = torch.empty(3, C, dtype=F32, device=dev)
-    N.call('mpr_bn_bwd_finalize', parts, parts.shape[0], rows, gamma.detach(), st.mean, st.invstd, dgamma, dbeta, acc,
-           coef, C)
+    _bwd_finalize(parts, rows, gamma, st, dgamma, dbeta, acc, coef, C, dev)
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
     N.call('mpr_bn_bwd_apply', dy, y, x, coef, st.scale, st.shift, mask_mode, dx, dz, rows, C)
@@ -482,11 +515,9 @@ def pool_bn_bwd(dpooled, idx, x, gamma, st, k=3, s=2, p=1, beta=None):
     parts = torch.empty(N.query('mpr_pool_bn_bwd_rows', B, H, W, C), 2, C, dtype=F32, device=dev)
     geo = (B, H, W, C, RH, RW, SH, SW, PH, PW)
     N.call('mpr_pool_bn_bwd', 0, dpooled, idx, x, st.scale, st.shift, st.mean, st.invstd, None, parts, None, *geo)
-    parts = _prereduce(parts)
     dgamma, dbeta, acc, ret = _bn_grad_targets(gamma, beta, C, dev)
     coef = torch.empty(3, C, dtype=F32, device=dev)
-    N.call('mpr_bn_bwd_finalize', parts, parts.shape[0], rows, gamma.detach(), st.mean, st.invstd, dgamma, dbeta, acc,
-           coef, C)
+    _bwd_finalize(parts, rows, gamma, st, dgamma, dbeta, acc, coef, C, dev)
     dx = torch.empty_like(x)
     N.call('mpr_pool_bn_bwd', 1, dpooled, idx, x, st.scale, st.shift, None, None, coef, None, dx, *geo)
     return dx, (dgamma if ret else None), (dbeta if ret else None)
