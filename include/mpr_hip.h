@@ -145,6 +145,17 @@ int mpr_bn_reduce_bwd_finalize(const float* partials, int nparts, float* slices,
                                long long count, const float* gamma, const float* mean, const float* invstd,
                                float* dgamma, float* dbeta, int accumulate, float* coef /* [3][C] */, int C,
                                void* stream);
+/* the finalize steps folded into their consumers (no launch of their own in the dependent chain): every workgroup of
+ * the apply kernel sums the `nsl` pre-reduced slice rows [nsl][2][C] itself; workgroup 0 writes what is needed later
+ * (scale / shift / mean / invstd + running statistics; dgamma / dbeta).  C <= 512. */
+int mpr_bn_apply_fin(const void* x, const float* slices, int nsl, long long count, const float* gamma, const float* beta,
+                     float* running_mean /* may be NULL */, float* running_var, float momentum, float eps, float* scale,
+                     float* shift, float* mean, float* invstd, const void* residual /* may be NULL */, int relu, void* y,
+                     long long rows, int C, void* stream);
+int mpr_bn_bwd_apply_fin(const void* dy, const void* y, const void* x, const float* slices, int nsl, long long count,
+                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                         int accumulate, const float* scale, const float* shift, int mask_mode, void* dx,
+                         void* dz_out /* may be NULL */, long long rows, int C, void* stream);
 int mpr_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coef, const float* scale,
                      const float* shift, int mask_mode, void* dx, void* dz_out /* may be NULL */, long long rows,
                      int C, void* stream);

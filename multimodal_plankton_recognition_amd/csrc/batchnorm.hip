@@ -192,18 +192,78 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
 }
 
 // y = [relu](x*scale + shift [+ res])
+// Finalize folded into the CONSUMER: every workgroup of the apply kernels sums the (few) pre-reduced slice rows itself
+// and derives the per-channel coefficients into LDS -- redundant arithmetic on a few KB of L2-resident data instead of a
+// 5-us launch in the dependent chain of every BatchNorm (which queues for 10-30 us behind the concurrent streams).
+// No cross-workgroup synchronisation: workgroup 0 alone writes the results anyone else needs later.
+//   MODE 0: lds[0] = scale, lds[1] = shift            MODE 1: lds[0..2] = k1, k2, k3 (dx = k1*dz + k2*x + k3)
+constexpr int FIN_MAX_C = 512;
+template <int MODE>
+__device__ __forceinline__ void bn_block_finalize(const float* __restrict__ slices, int nsl, int C, const BnFinalizeArgs& a,
+                                                  float (*lds)[FIN_MAX_C]) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < nsl; ++r) {
+      s1 += (double)slices[((size_t)r * 2) * C + c];
+      s2 += (double)slices[((size_t)r * 2 + 1) * C + c];
+    }
+    if (MODE == 0) {
+      const double mean = s1 / a.count;
+      double var = s2 / a.count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+      const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+      const float sc = g * invstd, sh = b - (float)mean * g * invstd;
+      lds[0][c] = sc;
+      lds[1][c] = sh;
+      if (blockIdx.x == 0) {
+        a.scale[c] = sc;
+        a.shift[c] = sh;
+        a.mean_out[c] = (float)mean;
+        a.invstd_out[c] = invstd;
+        if (a.running_mean) {
+          const double unbiased = a.count > 1.f ? var * (double)a.count / ((double)a.count - 1.0) : var;
+          a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+          a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+        }
+      }
+    } else {
+      const float sum_dz = (float)s1, sum_dzx = (float)s2;
+      const float g = a.gamma ? a.gamma[c] : 1.f, is = a.invstd_in[c], mu = a.mean_in[c];
+      const float k1 = g * is;
+      const float k2 = -g * is * is * sum_dzx / a.count;
+      lds[0][c] = k1;
+      lds[1][c] = k2;
+      lds[2][c] = -g * is * sum_dz / a.count - k2 * mu;
+      if (blockIdx.x == 0) {
+        if (a.dgamma) a.dgamma[c] = a.accumulate ? a.dgamma[c] + sum_dzx : sum_dzx;
+        if (a.dbeta) a.dbeta[c] = a.accumulate ? a.dbeta[c] + sum_dz : sum_dz;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const bf16_t* __restrict__ res, bf16_t* __restrict__ y,
-                                                       long long nvec, int cg) {
+                                                       long long nvec, int cg, const float* __restrict__ slices, int nsl,
+                                                       const BnFinalizeArgs fin) {
   // blockDim is a multiple of cg (host guarantees): the channel group is thread-invariant
   const int g = threadIdx.x % cg;
   float sc[8], sh[8];
-  *reinterpret_cast<float4*>(sc) = reinterpret_cast<const float4*>(scale)[g * 2];
-  *reinterpret_cast<float4*>(sc + 4) = reinterpret_cast<const float4*>(scale)[g * 2 + 1];
-  *reinterpret_cast<float4*>(sh) = reinterpret_cast<const float4*>(shift)[g * 2];
-  *reinterpret_cast<float4*>(sh + 4) = reinterpret_cast<const float4*>(shift)[g * 2 + 1];
+  __shared__ float fl[2][FIN_MAX_C];
+  if (slices) {          // statistics not finalized yet: do it here (see bn_block_finalize)
+    bn_block_finalize<0>(slices, nsl, cg * 8, fin, fl);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = fl[0][g * 8 + e]; sh[e] = fl[1][g * 8 + e]; }
+  } else {
+    *reinterpret_cast<float4*>(sc) = reinterpret_cast<const float4*>(scale)[g * 2];
+    *reinterpret_cast<float4*>(sc + 4) = reinterpret_cast<const float4*>(scale)[g * 2 + 1];
+    *reinterpret_cast<float4*>(sh) = reinterpret_cast<const float4*>(shift)[g * 2];
+    *reinterpret_cast<float4*>(sh + 4) = reinterpret_cast<const float4*>(shift)[g * 2 + 1];
+  }
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
        v += (long long)gridDim.x * blockDim.x) {
     float f[8];
@@ -324,15 +384,18 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ ymask, const bf16_t* __restrict__ x,
     const float* __restrict__ coef, const float* __restrict__ scale, const float* __restrict__ shift,
-    bf16_t* __restrict__ dx, bf16_t* __restrict__ dz_out, long long nvec, int C) {
+    bf16_t* __restrict__ dx, bf16_t* __restrict__ dz_out, long long nvec, int C, const float* __restrict__ slices,
+    int nsl, const BnFinalizeArgs fin) {
   const int cg = C >> 3;
   const int g = threadIdx.x % cg;   // blockDim is a multiple of cg
   float k1[8], k2[8], k3[8], sc[8], sh[8];
+  __shared__ float fl[3][FIN_MAX_C];
+  if (slices) bn_block_finalize<1>(slices, nsl, C, fin, fl);   // backward sums not finalized yet: do it here
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    k1[e] = coef[g * 8 + e];
-    k2[e] = coef[C + g * 8 + e];
-    k3[e] = coef[2 * C + g * 8 + e];
+    k1[e] = slices ? fl[0][g * 8 + e] : coef[g * 8 + e];
+    k2[e] = slices ? fl[1][g * 8 + e] : coef[C + g * 8 + e];
+    k3[e] = slices ? fl[2][g * 8 + e] : coef[2 * C + g * 8 + e];
     sc[e] = MODE == MASK_RECOMPUTE ? scale[g * 8 + e] : 0.f;
     sh[e] = MODE == MASK_RECOMPUTE ? shift[g * 8 + e] : 0.f;
   }
@@ -432,6 +495,17 @@ int mpr_bn_eval_coefs(const float* gamma, const float* beta, const float* runnin
   return MPR_OK;
 }
 
+static int launch_bn_apply(const bf16_t* xp, const float* scale, const float* shift, const bf16_t* rp, int relu,
+                           bf16_t* yp, long long nvec, int C, int grid, int BLK, const float* slices, int nsl,
+                           const BnFinalizeArgs& a, hipStream_t st) {
+  if (relu && rp) bn_apply_kernel<true, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  else if (relu) bn_apply_kernel<true, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  else if (rp) bn_apply_kernel<false, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  else bn_apply_kernel<false, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  MPR_LAUNCH_CHECK("bn_apply_kernel");
+  return MPR_OK;
+}
+
 int mpr_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, int relu, void* y,
                  long long rows, int C, void* stream) {
   MPR_REQUIRE(C % 8 == 0, "mpr_bn_apply: C must be a multiple of 8 (got %d)", C);
@@ -441,12 +515,26 @@ int mpr_bn_apply(const void* x, const float* scale, const float* shift, const vo
   hipStream_t st = (hipStream_t)stream;
   const bf16_t *xp = (const bf16_t*)x, *rp = (const bf16_t*)residual;
   bf16_t* yp = (bf16_t*)y;
-  if (relu && rp) bn_apply_kernel<true, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8);
-  else if (relu) bn_apply_kernel<true, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8);
-  else if (rp) bn_apply_kernel<false, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8);
-  else bn_apply_kernel<false, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8);
-  MPR_LAUNCH_CHECK("bn_apply_kernel");
-  return MPR_OK;
+  return launch_bn_apply(xp, scale, shift, rp, relu, yp, nvec, C, grid, BLK, nullptr, 0, BnFinalizeArgs{}, st);
+}
+
+// mpr_bn_finalize_stats folded into mpr_bn_apply: `slices` [nsl][2][C] are the (pre-reduced) partial sums; every
+// workgroup derives scale / shift itself, workgroup 0 also writes scale, shift, mean, invstd (for the backward pass)
+// and updates the running statistics.  C <= 512.
+int mpr_bn_apply_fin(const void* x, const float* slices, int nsl, long long count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                     float* mean, float* invstd, const void* residual, int relu, void* y, long long rows, int C,
+                     void* stream) {
+  MPR_REQUIRE(C % 8 == 0 && C <= FIN_MAX_C, "mpr_bn_apply_fin: C must be a multiple of 8, <= 512 (got %d)", C);
+  MPR_REQUIRE(slices && nsl > 0 && scale && shift && mean && invstd, "mpr_bn_apply_fin: null pointer");
+  const long long nvec = rows * C / 8;
+  const int BLK = cg_block(C / 8), grid = ew_grid(nvec, BLK);
+  BnFinalizeArgs a = {};
+  a.count = (float)count; a.momentum = momentum; a.eps = eps;
+  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.scale = scale; a.shift = shift; a.mean_out = mean; a.invstd_out = invstd;
+  return launch_bn_apply((const bf16_t*)x, scale, shift, (const bf16_t*)residual, relu, (bf16_t*)y, nvec, C, grid, BLK,
+                         slices, nsl, a, (hipStream_t)stream);
 }
 
 // mask_mode: 0 none, 1 relu mask from y (y > 0), 2 recompute relu mask from x*scale+shift
@@ -484,7 +572,33 @@ int mpr_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* 
   const long long nvec = rows * C / 8;
   const int BLK = cg_block(C / 8), grid = ew_grid(nvec, BLK);
   hipStream_t st = (hipStream_t)stream;
-#define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, coef, scale, shift, (bf16_t*)dx, (bf16_t*)dz_out, nvec, C
+#define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, coef, scale, shift, (bf16_t*)dx, (bf16_t*)dz_out, nvec, C, \
+             nullptr, 0, BnFinalizeArgs{}
+  if (mask_mode == MASK_NONE) bn_bwd_apply_kernel<MASK_NONE><<<grid, BLK, 0, st>>>(ARGS);
+  else if (mask_mode == MASK_Y) bn_bwd_apply_kernel<MASK_Y><<<grid, BLK, 0, st>>>(ARGS);
+  else bn_bwd_apply_kernel<MASK_RECOMPUTE><<<grid, BLK, 0, st>>>(ARGS);
+#undef ARGS
+  MPR_LAUNCH_CHECK("bn_bwd_apply_kernel");
+  return MPR_OK;
+}
+
+// mpr_bn_bwd_finalize folded into mpr_bn_bwd_apply: `slices` [nsl][2][C] are the (pre-reduced) sums of
+// mpr_bn_bwd_reduce; every workgroup derives the dx coefficients itself, workgroup 0 writes dgamma / dbeta.  C <= 512.
+int mpr_bn_bwd_apply_fin(const void* dy, const void* y, const void* x, const float* slices, int nsl, long long count,
+                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                         int accumulate, const float* scale, const float* shift, int mask_mode, void* dx, void* dz_out,
+                         long long rows, int C, void* stream) {
+  MPR_REQUIRE(C % 8 == 0 && C <= FIN_MAX_C, "mpr_bn_bwd_apply_fin: C must be a multiple of 8, <= 512 (got %d)", C);
+  MPR_REQUIRE(slices && nsl > 0 && mean && invstd, "mpr_bn_bwd_apply_fin: null pointer");
+  const long long nvec = rows * C / 8;
+  const int BLK = cg_block(C / 8), grid = ew_grid(nvec, BLK);
+  hipStream_t st = (hipStream_t)stream;
+  BnFinalizeArgs a = {};
+  a.count = (float)count;
+  a.gamma = gamma; a.mean_in = mean; a.invstd_in = invstd;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
+#define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, nullptr, scale, shift, (bf16_t*)dx, (bf16_t*)dz_out, nvec, C, \
+             slices, nsl, a
   if (mask_mode == MASK_NONE) bn_bwd_apply_kernel<MASK_NONE><<<grid, BLK, 0, st>>>(ARGS);
   else if (mask_mode == MASK_Y) bn_bwd_apply_kernel<MASK_Y><<<grid, BLK, 0, st>>>(ARGS);
   else bn_bwd_apply_kernel<MASK_RECOMPUTE><<<grid, BLK, 0, st>>>(ARGS);

@@ -53,8 +53,8 @@ class BatchNormParams(nn.Module):
         self._pending += 1
 
 
-def _bn_coefs(stats, count, bn, train, x=None):
-    st = ops.bn_coefs(stats, count, bn, train, x)
+def _bn_coefs(stats, count, bn, train, x=None, defer=False):
+    st = ops.bn_coefs(stats, count, bn, train, x, defer=defer)
     if train:
         bn.count_batch()
     return st
@@ -118,14 +118,14 @@ class BasicBlockFn(torch.autograd.Function):
         wf1, wd1 = ops.packed_weights(w1, c1, need_bwd)
         wf2, wd2 = ops.packed_weights(w2, c2, need_bwd)
         x1, s1 = ops.conv_fwd(x, wf1, c1, train)
-        st1 = _bn_coefs(s1, _rows(x1), mod.bn1, train, x1)
+        st1 = _bn_coefs(s1, _rows(x1), mod.bn1, train, x1, defer=True)     # finalized inside the bn_apply that follows
         a1 = ops.bn_apply(x1, st1, None, True)
         x2, s2 = ops.conv_fwd(a1, wf2, c2, train)
-        st2 = _bn_coefs(s2, _rows(x2), mod.bn2, train, x2)
+        st2 = _bn_coefs(s2, _rows(x2), mod.bn2, train, x2, defer=True)
         if wd is not None:
             wfd, wdd = ops.packed_weights(wd, cd, need_bwd)
             xd, sd = ops.conv_fwd(x, wfd, cd, train)
-            std = _bn_coefs(sd, _rows(xd), mod.downsample[1], train, xd)
+            std = _bn_coefs(sd, _rows(xd), mod.downsample[1], train, xd, defer=True)
             identity = ops.bn_apply(xd, std, None, False)
         else:
             xd = std = wdd = None

@@ -390,26 +390,35 @@ def _ticket(dev):
     return pool[0][pool[1]:pool[1] + 1]
 
 
-def _prereduce(parts):
-    """Long per-workgroup partial lists are folded to 64 rows first (spreads the read over the chip)."""
+def _prereduce(parts, nsplit=64, limit=512):
+    """Long per-workgroup partial lists are folded to `nsplit` rows first (spreads the read over the chip)."""
     n, _, C = parts.shape
-    if n <= 512:
+    if n <= limit:
         return parts
-    out = torch.empty(64, 2, C, dtype=F32, device=parts.device)
-    N.call('mpr_bn_reduce_partials', parts, n, out, 64, C)
+    out = torch.empty(nsplit, 2, C, dtype=F32, device=parts.device)
+    N.call('mpr_bn_reduce_partials', parts, n, out, nsplit, C)
     return out
 
 
+# BatchNorm finalize folded into the consuming apply kernel (mpr_bn_apply_fin / mpr_bn_bwd_apply_fin): the partial sums
+# are pre-reduced to FIN_SLICES rows and every workgroup of the apply kernel finishes them itself.
+FIN_IN_CONSUMER = os.environ.get('MPR_FIN_IN_CONSUMER', '1') != '0'
+FIN_SLICES = 8
+
+
 class BNState:
-    """Per-call BatchNorm coefficients: scale/shift always, mean/invstd in train mode."""
-    __slots__ = ('scale', 'shift', 'mean', 'invstd')
+    """Per-call BatchNorm coefficients: scale/shift always, mean/invstd in train mode.  `pending`: the statistics are
+    still (pre-reduced) partial sums -- the first bn_apply finalizes them inside its own kernel."""
+    __slots__ = ('scale', 'shift', 'mean', 'invstd', 'pending')
 
 
-def bn_coefs(stats, count, bn, train, x=None):
-    """bn: object with weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps."""
+def bn_coefs(stats, count, bn, train, x=None, defer=False):
+    """bn: object with weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps.
+    defer=True: the caller promises that the next use of the result is ops.bn_apply (which then finalizes)."""
     C = bn.weight.shape[0]
     dev = bn.weight.device
     st = BNState()
+    st.pending = None
     st.scale = torch.empty(C, dtype=F32, device=dev)
     st.shift = torch.empty(C, dtype=F32, device=dev)
     if train:
@@ -419,7 +428,9 @@ def bn_coefs(stats, count, bn, train, x=None):
             N.call('mpr_bn_stats', x, stats, rows, C)
         st.mean = torch.empty(C, dtype=F32, device=dev)
         st.invstd = torch.empty(C, dtype=F32, device=dev)
-        if FUSED_FINALIZE and stats.shape[0] > 512:
+        if defer and FIN_IN_CONSUMER and C <= 512:
+            st.pending = (_prereduce(stats, FIN_SLICES, FIN_SLICES), count, bn)
+        elif FUSED_FINALIZE and stats.shape[0] > 512:
             # long partial list: pre-reduction and finalize in one launch (the last workgroup finalizes)
             slices = torch.empty(64, 2, C, dtype=F32, device=dev)
             N.call('mpr_bn_reduce_finalize_stats', stats, stats.shape[0], slices, 64, _ticket(dev), count,
@@ -440,6 +451,13 @@ def bn_coefs(stats, count, bn, train, x=None):
 def bn_apply(x, st, residual=None, relu=True):
     C = x.shape[-1]
     y = torch.empty_like(x)
+    if st.pending is not None:
+        slices, count, bn = st.pending
+        st.pending = None
+        N.call('mpr_bn_apply_fin', x, slices, slices.shape[0], count, bn.weight.detach(), bn.bias.detach(),
+               bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps), st.scale, st.shift, st.mean,
+               st.invstd, residual, int(relu), y, x.numel() // C, C)
+        return y
     N.call('mpr_bn_apply', x, st.scale, st.shift, residual, int(relu), y, x.numel() // C, C)
     return y
 
@@ -474,10 +492,15 @@ def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False, beta=None):
     parts = torch.empty(N.query('mpr_bn_reduce_rows', rows, C), 2, C, dtype=F32, device=dev)
     N.call('mpr_bn_bwd_reduce', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, rows, C)
     dgamma, dbeta, acc, ret = _bn_grad_targets(gamma, beta, C, dev)
-    coef = torch.empty(3, C, dtype=F32, device=dev)
-    _bwd_finalize(parts, rows, gamma, st, dgamma, dbeta, acc, coef, C, dev)
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
+    if FIN_IN_CONSUMER and C <= 512:
+        slices = _prereduce(parts, FIN_SLICES, FIN_SLICES)
+        N.call('mpr_bn_bwd_apply_fin', dy, y, x, slices, slices.shape[0], rows, gamma.detach(), st.mean, st.invstd,
+               dgamma, dbeta, acc, st.scale, st.shift, mask_mode, dx, dz, rows, C)
+        return dx, (dgamma if ret else None), (dbeta if ret else None), dz
+    coef = torch.empty(3, C, dtype=F32, device=dev)
+    _bwd_finalize(parts, rows, gamma, st, dgamma, dbeta, acc, coef, C, dev)
     N.call('mpr_bn_bwd_apply', dy, y, x, coef, st.scale, st.shift, mask_mode, dx, dz, rows, C)
     return dx, (dgamma if ret else None), (dbeta if ret else None), dz
 
