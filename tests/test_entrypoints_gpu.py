@@ -118,3 +118,25 @@ def test_dp_step_world1_equals_single_gpu_step():
                 assert torch.allclose(v, results[1][1][k], rtol=1e-4, atol=1e-6), k
     finally:
         D.shutdown()
+
+
+def test_export_embeddings_schema_and_normalisation(tmp_path):
+    """predict_step + L2-normalise over folds, in the pickle schema the reference's benchmarks read."""
+    import pickle
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import export_embeddings as E
+    out = tmp_path / 'emb.pkl'
+    res = E.main(['-m', os.path.join(ROOT, 'model_cards', 'smoke_multi.yaml'), '-o', str(out), '--synthetic', '24',
+                  '--batch', '8'])
+    loaded = pickle.load(open(out, 'rb'))
+    assert list(loaded) == ['smoke_multi'] and set(loaded['smoke_multi']) == {'fold_0', 'fold_1'}
+    for fold in loaded['smoke_multi'].values():
+        assert set(fold) == {'image', 'profile', 'label', 'classes'}
+        n, d = fold['image'].shape
+        assert n == 24 and fold['profile'].shape == (n, d) and len(fold['label']) == n
+        np.testing.assert_allclose(np.linalg.norm(fold['image'], axis=1), 1.0, rtol=1e-5)
+        np.testing.assert_allclose(np.linalg.norm(fold['profile'], axis=1), 1.0, rtol=1e-5)
+        assert set(fold['label']) <= set(fold['classes'])
+    assert np.array_equal(res['smoke_multi']['fold_0']['image'], loaded['smoke_multi']['fold_0']['image'])
