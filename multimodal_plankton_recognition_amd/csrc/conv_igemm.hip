@@ -702,7 +702,7 @@ int mpr_conv_pack_weights_multi(const void* table, int n, void* stream) {
 // shifted-window kernel for 3x3 / stride 1 / pad 1 (conv_win.hip)
 bool mpr_win_eligible(long long M, int H, int W, int srcC, int Nout, int R, int S, int sh, int sw, int ph, int pw,
                       long long min_rows);
-int mpr_win_tiles(int B, int H, int W);
+int mpr_win_stat_rows(int B, int H, int W, int Nout);
 int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, const void* add, float* stats, int B, int H,
                    int W, int srcC, int Nout, hipStream_t st);
 
@@ -855,7 +855,7 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
 // Number of row tiles (= rows of the BatchNorm partial-sum buffer) mpr_conv_fwd will use.
 int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S, int sh, int sw, int ph, int pw) {
   if (mpr_win_eligible((long long)B * P * Q, P, Q, C, K, R, S, sh, sw, ph, pw, g_dma_min_rows))   // (stride 1: H == P)
-    return mpr_win_tiles(B, P, Q);
+    return mpr_win_stat_rows(B, P, Q, K);
   int mode, BM, BN;
   igemm_config((long long)B * P * Q, K, C, R * S, &mode, &BM, &BN);
   return ceil_div(B * P * Q, BM);

@@ -384,6 +384,237 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams 
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent form of the 256 x 64 tile (N <= 64: ResNet layer1, whose 9-chunk loop is shorter than the tile's own
+// prologue + epilogue).  One workgroup per (CU, slot) walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...:
+//   * the NEXT tile's window DMA is issued as soon as the loop of the current tile ends -- it lands underneath the
+//     epilogue instead of in front of the next loop;
+//   * the epilogue needs no workgroup barrier: every wave stages its own 64 x 64 block, 32 rows at a time, in a private
+//     4 KB slice of LDS (rounded to bf16; the fused residual path of the data gradient stays on the plain kernel, it
+//     must see the unrounded accumulator) and stores finished 128-B rows;
+//   * the weight ring (2 stages) simply runs on across tiles;
+//   * BatchNorm partial sums stay in registers over all tiles of the workgroup: gridDim.x partial rows per conv.
+// LDS: window | 2 x 8 KB weight stages | 4 x 4 KB staging  (<= 80 KB: two workgroups per CU).
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void conv_win_persist_kernel(const WinParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = 4, BM = 256, BN = 64, TM = 2, TN = 2;
+  constexpr int WI_MAX = (BM + 2 * 58 + 7) / 8, WIW = (WI_MAX + NW - 1) / NW;
+  constexpr int B_IT = BN / 8 / NW;
+  constexpr int BSTAGE = BN * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid;
+  const int wrows8 = (p.wrows + 7) & ~7;
+  unsigned char* const bring = smem + wrows8 * 128;
+  unsigned char* const stage = bring + 2 * BSTAGE + wid * 4096;      // this wave's private 32 x 128 B
+  const int ntiles = (p.Gtot + BM - 1) / BM;
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, p.wpk_bytes, 0x00020000);
+  uint32_t boff[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int q = wid * B_IT + j;
+    const int lc = (lane & 7) ^ ((4 * q + (lane >> 4)) & 7);
+    boff[j] = ((uint32_t)(8 * q + (lane >> 3)) * (uint32_t)p.Kgpad + lc * 8) * 2;
+  }
+  uint32_t wvoff[WIW];
+  uint32_t wmask = 0;
+  auto decode_window = [&](int G0) {
+    wmask = 0;
+#pragma unroll
+    for (int k = 0; k < WIW; ++k) {
+      const int I = wid + k * NW;
+      const int j = 8 * I + (lane >> 3);
+      const int G = G0 - p.halo + j;
+      wvoff[k] = 0;
+      if (j < p.wrows && G >= 0 && G < p.Gtot) {
+        const uint32_t b = fdiv(G, p.div_img);
+        const uint32_t pp = G - b * p.img;
+        const uint32_t hh = fdiv(pp, p.div_wp);
+        const uint32_t ww = pp - hh * p.Wp;
+        if (hh < (uint32_t)p.H && ww < (uint32_t)p.W) {
+          const uint32_t pix = (b * p.H + hh) * p.W + ww;
+          const int lc = (lane & 7) ^ ((4 * I + (lane >> 4)) & 7);
+          wvoff[k] = pix * (uint32_t)(2 * p.C) + lc * 16;
+          wmask |= 1u << k;
+        }
+      }
+    }
+  };
+  auto issue_window = [&](int cb) {
+#pragma unroll
+    for (int k = 0; k < WIW; ++k) {
+      const int I = wid + k * NW;
+      if (8 * I < wrows8) {
+        const uint32_t v = ((wmask >> k) & 1u) ? wvoff[k] + cb * 128 : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(smem + I * 1024), 16, v,
+                                                 0, 0, 0);
+      }
+    }
+  };
+  auto issue_weights = [&](int tap, int cb, int st) {
+    const int soff = (tap * p.ncb + cb) * 128;
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_b, (__attribute__((address_space(3))) void*)(bring + st * BSTAGE + (wid * B_IT + j) * 1024), 16, boff[j],
+          soff, 0, 0);
+  };
+
+  const int frow = lane & 31, fh = lane >> 5;
+  const int baseA = wm * (TM * 32) + frow + p.halo;
+  uint32_t b_rd[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b_rd[j][ks] = win_swz(j * 32 + frow, ks * 2 + fh);
+
+  // epilogue read geometry: lane -> (row lane/8 + 8*it, 16-B chunk lane%8); its 8 channels are fixed over the kernel
+  const int erow = lane >> 3, ech = lane & 7;
+  const bool col_ok = ech * 8 < p.Nout;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+
+  const int nk = 9 * p.ncb;
+  int gk = 0;                                   // chunks done by this workgroup (weight ring position)
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    decode_window(tile * BM);
+    issue_window(0);
+    issue_weights(0, 0, 0);
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int G0 = tile * BM;
+    const bool more = tile + (int)gridDim.x < ntiles;
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+    int tap = 0, cb = 0, tr = 0, ts = 0;
+    for (int kc = 0; kc < nk; ++kc, ++gk) {
+      if (tap == 0 && cb > 0) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_window(cb);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int d = DGRAD ? (1 - tr) * p.Wp + (1 - ts) : (tr - 1) * p.Wp + (ts - 1);
+      const int rowA = baseA + d;
+      const int key = (rowA >> 1) & 7;
+      const unsigned char* const arow = smem + rowA * 128;
+      const unsigned char* const bst = bring + (gk & 1) * BSTAGE;
+      bf16x8 af[2][TM], bfr[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(arow + i * 4096 + ((fh ^ key) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(bst + b_rd[j][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      {   // weights of the next chunk of the ring -- the first chunk of the next tile after the last one of this tile
+        int ntap = tap + 1, ncb2 = cb;
+        if (ntap == 9) { ntap = 0; ++ncb2; }
+        if (ncb2 == p.ncb) { ntap = 0; ncb2 = 0; }
+        if (kc + 1 < nk || more) issue_weights(ntap, ncb2, (gk + 1) & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks < 3) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            af[nxt][i] = *reinterpret_cast<const bf16x8*>(arow + i * 4096 + (((2 * (ks + 1) + fh) ^ key) << 4));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(bst + b_rd[j][ks + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (++ts == 3) { ts = 0; ++tr; }
+      if (++tap == 9) { tap = 0; tr = 0; ++cb; }
+    }
+    // every wave is done with this tile's window: the next tile's goes out now and lands underneath the epilogue
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (more) {
+      decode_window(G0 + (int)gridDim.x * BM);
+      issue_window(0);
+    }
+    // ---- epilogue, wave-private: 32 rows x 64 channels at a time through this wave's 4 KB of LDS
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 v;
+          v.x = pack_bf16x2(acc[j][i][4 * g], acc[j][i][4 * g + 1]);
+          v.y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+          *reinterpret_cast<uint2*>(stage + frow * 128 + (((4 * j + g) ^ (frow & 7)) << 4) + fh * 8) = v;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private: no barrier
+      uint4 pk[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = erow + 8 * it;
+        pk[it] = *reinterpret_cast<const uint4*>(stage + r * 128 + ((ech ^ (r & 7)) << 4));
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int G = G0 + wm * 64 + i * 32 + erow + 8 * it;
+        const uint32_t Gc = G < p.Gtot ? G : 0;
+        const uint32_t b = fdiv(Gc, p.div_img);
+        const uint32_t pp = Gc - b * p.img;
+        const uint32_t hh = fdiv(pp, p.div_wp);
+        const uint32_t ww = pp - hh * p.Wp;
+        if (col_ok && G < p.Gtot && hh < (uint32_t)p.H && ww < (uint32_t)p.W) {
+          *reinterpret_cast<uint4*>(p.dst + (size_t)((b * p.H + hh) * p.W + ww) * p.Nout + ech * 8) = pk[it];
+          if (p.stats) {
+            float q[8];
+            unpack8(pk[it], q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the slice is rewritten
+    }
+  }
+  if (p.stats) {
+    // one partial row per workgroup: [T][16 (+1)] -> 8 channel groups x 16 values, 32 threads each
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[tid * 17 + e] = s1[e];
+      red[tid * 17 + 8 + e] = s2[e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid >> 4, e = tid & 15;            // channel group (lane % 8 == c), value
+      float v = 0.f;
+      for (int q = 0; q < 32; ++q) v += red[(q * 8 + c) * 17 + e];
+      const int n = c * 8 + (e & 7);
+      if (n < p.Nout) p.stats[((size_t)blockIdx.x * 2 + (e >> 3)) * p.Nout + n] = v;
+    }
+  }
+#endif   // __HIP_DEVICE_COMPILE__
+}
+
 static unsigned long long* g_win_probe = nullptr;
 extern "C" int mpr_conv_debug_probe(void* buf) {   // 8 x uint64 per workgroup of the next window-kernel launches
   g_win_probe = (unsigned long long*)buf;
@@ -411,7 +642,17 @@ bool mpr_win_eligible(long long M, int H, int W, int srcC, int Nout, int R, int 
          W >= 2 && W <= 56 && H >= 2 && M >= min_rows && (long long)(M / (H * W)) * (H + 1) * (W + 1) < (1ll << 30);
 }
 
-int mpr_win_tiles(int B, int H, int W) { return ceil_div(B * (H + 1) * (W + 1), 256); }
+// N <= 64 forward: persistent kernel (variant bit 6 switches it off, bit 7 extends it to plain data gradients).
+// Measured at batch 512, 64 -> 64 @ 56x56: forward 192 us vs 204 us, data gradient 215 us vs 190 us -- forward only.
+static inline bool win_persistent(bool dgrad, int Nout, const void* add) {
+  return !(g_win_variant & 64) && Nout <= 64 && add == nullptr && (!dgrad || (g_win_variant & 128));
+}
+
+// rows of the BatchNorm partial-sum buffer the forward launch will write
+int mpr_win_stat_rows(int B, int H, int W, int Nout) {
+  const int tiles = ceil_div(B * (H + 1) * (W + 1), 256);
+  return win_persistent(false, Nout, nullptr) ? (tiles < 512 ? tiles : 512) : tiles;
+}
 
 // src [B,H,W,srcC] (*) panel [Npad128][9*srcC] -> dst [B,H,W,Nout]  (dgrad: mirrored tap shifts)
 int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, const void* add, float* stats, int B, int H,
@@ -434,6 +675,27 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
   p.ntn = ceil_div(Nout, BN);
   const int tiles_m = ceil_div(p.Gtot, 256);
   const size_t wbytes = (size_t)((p.wrows + 7) / 8 * 8) * 128;
+  if (win_persistent(dgrad, Nout, add)) {
+    p.ntn = 1;
+    const size_t lds = wbytes + 2 * 8192 + 4 * 4096;
+    const int grid_p = tiles_m < 512 ? tiles_m : 512;
+    static bool attr_set[2] = {false, false};
+    if (dgrad) {
+      if (!attr_set[1]) {
+        hipFuncSetAttribute((const void*)conv_win_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[1] = true;
+      }
+      conv_win_persist_kernel<true><<<grid_p, 256, lds, st>>>(p);
+    } else {
+      if (!attr_set[0]) {
+        hipFuncSetAttribute((const void*)conv_win_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[0] = true;
+      }
+      conv_win_persist_kernel<false><<<grid_p, 256, lds, st>>>(p);
+    }
+    MPR_LAUNCH_CHECK("conv_win_persist_kernel");
+    return MPR_OK;
+  }
   const size_t lds_pad = (g_win_variant & 16) ? 40 * 1024 : 0;   // experiment: force one workgroup per CU
   const int g_win_variant_ = g_win_variant & 15;
   dim3 grid(tiles_m * p.ntn);
