@@ -26,14 +26,20 @@ CARD = os.path.join(ROOT, 'model_cards', 'resnet18_cnn_2_512_clip.yaml')
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
-def synthetic_batch(B, T, device, seed):
-    """image ~ clamp(N(0.6136, 0.0938), 0, 1)*2-1, profile ~ U[-1, 1]."""
+def synthetic_batch(B, T, device, seed, transformer=False):
+    """image ~ clamp(N(0.6136, 0.0938), 0, 1)*2-1, profile ~ U[-1, 1]
+    (transformer profile encoder: + prepended zero CLS row, time = arange(T + 1), all-False padding mask)."""
     g = torch.Generator(device=device).manual_seed(seed)
     image = (torch.randn(B, 1, T, T, generator=g, device=device) * 0.0938 + 0.6136).clamp_(0, 1) * 2 - 1
     profile = torch.rand(B, T, 6, generator=g, device=device) * 2 - 1
     image_shape = torch.randint(32, 401, (B, 2), generator=g, device=device)
     profile_len = torch.randint(8, 1025, (B, 1), generator=g, device=device)
-    return {'image': image, 'profile': profile, 'image_shape': image_shape, 'profile_len': profile_len}
+    batch = {'image': image, 'profile': profile, 'image_shape': image_shape, 'profile_len': profile_len}
+    if transformer:
+        batch['profile'] = torch.cat((torch.zeros(B, 1, 6, device=device), profile), 1)
+        batch['time'] = torch.arange(T + 1, device=device).repeat(B, 1)
+        batch['padding_mask'] = torch.zeros(B, T + 1, dtype=torch.bool, device=device)
+    return batch
 
 
 def isolated_conv_rate(B, dev):

@@ -213,6 +213,44 @@ int mpr_embedding_bwd(const float* dy, const long long* index, float* dtable, in
                       long long padding_idx, void* stream);
 int mpr_add_f32(const float* a, const float* b, float* y, long long n, void* stream);
 
+/* ---- transformer encoder pieces, mixed precision (trainer precision 'bf16-mixed' / '16-mixed': fp32 residual
+ *      stream, bf16 GEMM operands; same reference call sites as the fp32 block above).  The linears of a block run on
+ *      mpr_conv_fwd / mpr_conv_dgrad / mpr_conv_wgrad as 1x1 convolutions; these entry points are what sits between
+ *      them.  Dropout masks are not stored: element i is kept iff hash(seed, i) >= p (regenerated in backward). */
+/* s = x + drop(r + rbias) [-> s_out];  y = LayerNorm(s) * gamma + beta -> y32 and / or y16 (gamma NULL: add only).
+ * x, s_out, y32 fp32 [rows][D]; r, y16 bf16; D % 4 == 0, D <= 2048 */
+int mpr_tf_add_ln_fwd(const float* x /* NULL: zeros */, const void* r /* may be NULL */, const float* rbias /* may be NULL */, float p_drop,
+                      unsigned seed, const float* gamma /* may be NULL */, const float* beta, float eps,
+                      float* s_out /* may be NULL */, float* y32 /* may be NULL */, void* y16 /* may be NULL */,
+                      float* mean, float* rstd, int rows, int D, void* stream);
+int mpr_tf_ln_bwd_workspace_floats(int rows, int D);
+/* ds = dLN/ds of the gradient (dy16 bf16 [+ dy32 fp32]) (+ dskip); dgamma / dbeta assigned or accumulated; D <= 1024 */
+int mpr_tf_ln_bwd(const void* dy16 /* may be NULL */, const float* dy32 /* may be NULL */, const float* s, const float* gamma,
+                  const float* mean, const float* rstd, const float* dskip /* may be NULL */, float* ds, float* dgamma,
+                  float* dbeta, float* workspace, int accumulate, int rows, int D, void* stream);
+/* y = drop(act(x + bias)), bf16 -> bf16 [rows][D], D % 8 == 0; act: 0 none, 1 exact GELU, 2 ReLU */
+int mpr_tf_bias_act_fwd(const void* x, const float* bias /* may be NULL */, int act, float p_drop, unsigned seed, void* y,
+                        long long rows, int D, void* stream);
+/* backward elementwise passes fused with the column sums of a bias gradient (added into dbias):
+ * mode 0: dbias += colsum(dy bf16);  mode 1: dx = dy * dropmask/(1-p) * act'(x + bias) (bf16), dbias += colsum(dx);
+ * mode 2: dx = bf16(dy fp32 * dropmask/(1-p)), dbias += colsum(dx).  dbias may be NULL in modes 1 and 2. */
+int mpr_tf_ew_bwd_workspace_floats(int rows, int D);
+int mpr_tf_ew_bwd(int mode, const void* dy, const void* x /* mode 1 */, const float* bias, int act, float p_drop,
+                  unsigned seed, void* dx, float* dbias, float* workspace /* needed iff dbias */, int rows, int D,
+                  void* stream);
+/* fused multi-head self-attention on a packed bf16 qkv [B][T][3*heads*head_dim] (torch MHA / timm layout) whose
+ * in-projection bias is added while the operands are loaded; key-padding mask [B][T] bytes; T <= 256, head_dim 32 | 64.
+ * out bf16 [B][T][heads*head_dim]; lse fp32 [B*heads][T] is kept for backward; delta: [B*heads][T] scratch */
+int mpr_attn_supported(int T, int head_dim);
+int mpr_attn_fwd(const void* qkv, const float* bias /* may be NULL */, const void* key_padding_mask /* may be NULL */,
+                 void* out, float* lse, int B, int T, int heads, int head_dim, float scale, float p_drop, unsigned seed,
+                 void* stream);
+int mpr_attn_bwd(const void* qkv, const float* bias, const void* key_padding_mask, const void* out, const void* dout,
+                 const float* lse, float* delta, void* dqkv, int B, int T, int heads, int head_dim, float scale,
+                 float p_drop, unsigned seed, void* stream);
+/* fp32 -> bf16 (to_bf16 != 0) or bf16 -> fp32; n % 4 == 0 */
+int mpr_tf_cast(const void* x, void* y, long long n, int to_bf16, void* stream);
+
 /* ---- coordination losses (src/coordination.py:17-112) ----------------------------------------- */
 int mpr_loss_workspace_floats(void);
 int mpr_l2norm_fwd(const float* x, float* u, float* inv_norm, int rows, int D, void* stream);

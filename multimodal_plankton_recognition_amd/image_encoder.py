@@ -119,7 +119,11 @@ class ViTBackbone(nn.Module):
         gh, gw = H // P, W // P
         # conv-as-GEMM patch embedding: [B, gh*gw, C*P*P] x [d, C*P*P]^T
         patches = image.float().reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * P * P)
-        x = linear(patches.contiguous(), self.patch_embed.proj.weight.view(d, -1), self.patch_embed.proj.bias)
+        if TF.mixed() and (C * P * P) % 8 == 0 and d % 8 == 0:
+            from .transformer_mixed import LinearMixedFn
+            x = LinearMixedFn.apply(patches.contiguous(), self.patch_embed.proj.weight.view(d, -1), self.patch_embed.proj.bias)
+        else:
+            x = linear(patches.contiguous(), self.patch_embed.proj.weight.view(d, -1), self.patch_embed.proj.bias)
         x = torch.cat((self.cls_token.expand(B, 1, d), x.view(B, gh * gw, d)), 1).contiguous()
         T = x.shape[1]
         index = torch.arange(T, device=x.device).repeat(B)

@@ -28,8 +28,12 @@ def _like_spatial(x, B, P, Q, K):
 class ConvGeom:
     """Static description of one convolution (torch OIHW / OIW weight)."""
 
-    def __init__(self, weight_shape, stride, pad):
-        if len(weight_shape) == 3:       # Conv1d [K, C, S]
+    def __init__(self, weight_shape, stride=1, pad=0):
+        if len(weight_shape) == 2:       # nn.Linear [K, C] == a 1x1 convolution over the token axis
+            self.K, self.C = weight_shape
+            self.R = self.S = self.sh = self.sw = 1
+            self.ph = self.pw = 0
+        elif len(weight_shape) == 3:     # Conv1d [K, C, S]
             self.K, self.C, self.S = weight_shape
             self.R, self.sh, self.sw, self.ph, self.pw = 1, 1, stride, 0, pad
         else:
@@ -52,11 +56,15 @@ _pack_cache = {}
 def _kcrs_strides(weight):
     """Element strides (sk, sc, sr, ss) of a conv weight viewed as [K, C, R, S] (Conv1d: R == 1)."""
     st = weight.stride()
+    if weight.dim() == 2:
+        return (st[0], st[1], 0, 0)
     return (st[0], st[1], 0, st[2]) if weight.dim() == 3 else tuple(st)
 
 
 def is_krsc(weight):
     """True when the weight's MEMORY is [K][R][S][C] (channels-last): what conv_wgrad produces natively."""
+    if weight.dim() == 2:
+        return weight.is_contiguous()
     if weight.dim() == 3:
         K, C, S = weight.shape
         return tuple(weight.stride()) == (S * C, 1, C)

@@ -113,8 +113,7 @@ class ProfileTransformer(nn.Module):
         d = self.expand.weight.shape[0]
         x = linear(profile.reshape(B * T, -1).float().contiguous(), self.expand.weight)
         x = TF.EmbeddingAddFn.apply(x, self.position.weight, time, self.padding_idx).view(B, T, d)
-        for layer in self.encoder.layers:
-            x = TF.post_norm_layer(layer, x, padding_mask, self.p_drop, self.training)
+        x = TF.post_norm_stack(self.encoder.layers, x, padding_mask, self.p_drop, self.training)
         cls = x[:, 0].contiguous()
         meta = kwargs['profile_len'].contiguous() if self.metadata else None
         return TailFn.apply(cls, meta, profile.shape[1], self.p_drop if self.training else 0.0)

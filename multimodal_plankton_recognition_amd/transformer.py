@@ -16,6 +16,24 @@ from .layers import linear, next_seed
 
 F32 = torch.float32
 
+# 'fp32': every transformer GEMM on the exact-fp32 MFMA kernel (parity with the reference's CPU path at rtol 2e-4);
+# 'bf16-mixed': fp32 residual stream, bf16 GEMM operands on the bf16 MFMA kernels, fused attention (transformer_mixed.py)
+# -- what Lightning's `precision: 16-mixed` / `bf16-mixed` of the reference cards means on this hardware.
+_PRECISION = ['fp32']
+
+
+def set_precision(precision):
+    """Trainer / card `precision` -> transformer arithmetic.  Returns the previous mode."""
+    old = _PRECISION[0]
+    name = str(precision).lower() if precision is not None else '32'
+    _PRECISION[0] = 'bf16-mixed' if ('16' in name and 'mixed' in name) or name in ('bf16', '16', 'bf16-true', '16-true') \
+        else 'fp32'
+    return old
+
+
+def mixed():
+    return _PRECISION[0] == 'bf16-mixed'
+
 
 class AddLayerNormFn(torch.autograd.Function):
     """y = LayerNorm(x + residual) (residual may be None).  Both inputs receive the same gradient."""
@@ -216,6 +234,9 @@ def post_norm_layer(layer, x, key_padding_mask, p_drop, training):
 
 def pre_norm_block(blk, x, heads, p_drop, training):
     """One timm ViT block: x += proj(attn(LN(x))); x += fc2(gelu(fc1(LN(x))))."""
+    if mixed():
+        from . import transformer_mixed
+        return transformer_mixed.pre_norm_block(blk, x, heads, p_drop, training)
     B, T, d = x.shape
     p = p_drop if training else 0.0
     x2 = x.reshape(B * T, d)
@@ -229,3 +250,16 @@ def pre_norm_block(blk, x, heads, p_drop, training):
     h = linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
     x2 = AddFn.apply(x2, activation_dropout(h, 'none', p))
     return x2.view(B, T, d)
+
+
+def post_norm_stack(layers, x, key_padding_mask, p_drop, training):
+    """A stack of torch post-norm encoder layers (nn.TransformerEncoder without final norm)."""
+    if mixed():
+        from . import transformer_mixed
+        x16 = None
+        for layer in layers:
+            x, x16 = transformer_mixed.post_norm_layer(layer, x, x16, key_padding_mask, p_drop, training)
+        return x
+    for layer in layers:
+        x = post_norm_layer(layer, x, key_padding_mask, p_drop, training)
+    return x
