@@ -275,6 +275,20 @@ int mpr_siglip_bwd(float* S, const float* logit_scale, const float* bias, const 
                    float* d_bias, float* workspace, int buckets, int n, void* stream);
 int mpr_mse_add(const float* a, const float* b, float beta, float* loss, float* workspace, long long total,
                 void* stream);
+/* RankLoss (src/coordination.py:115-135) on the raw cosine matrix S [n][n] (diagonal negated on the fly):
+ * row / column sums, loss = (mean relu(margin + colsum) + mean relu(margin + rowsum)) / 2, and dL/dS */
+int mpr_rank_fwd(const float* S, float margin, float* row_sum, float* col_sum, float* loss, int n, void* stream);
+int mpr_rank_bwd(float* G /* [n][n] out */, const float* row_sum, const float* col_sum, float margin,
+                 const float* gout /* [1] or NULL */, int n, void* stream);
+
+/* ---- ProfileLSTM (src/profile_encoder.py:71-108): pointwise cell of nn.LSTM, gate order i, f, g, o; the input and
+ *      recurrent projections run on mpr_gemm_f32 (time-major: step t is a contiguous [B][4d] slice) */
+int mpr_lstm_cell_fwd(const float* G /* [B][4d] x W_ih^T + b_ih + h_prev W_hh^T */, const float* b_hh,
+                      const float* c_prev /* NULL: zeros */, float* act /* [B][4d] gate activations, kept for backward */,
+                      float* c, float* h, int B, int d, void* stream);
+int mpr_lstm_cell_bwd(const float* act, const float* c_prev /* NULL: zeros */, const float* c, const float* dh_a,
+                      const float* dh_b /* may be NULL */, float* dc /* in: d c_t from step t+1, out: d c_{t-1} */,
+                      float* dG /* [B][4d] */, int B, int d, void* stream);
 
 /* ---- optimiser, encoder tail, classifier loss --------------------------------------------------
  * optim.SGD over all parameters (src/model.py:147-148); metadata concat + dropout

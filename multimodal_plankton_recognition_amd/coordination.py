@@ -162,14 +162,42 @@ class SigLIPPlus(nn.Module):
                                float(self.beta))
 
 
+class _RankFn(torch.autograd.Function):
+    """src/coordination.py:124-135."""
+
+    @staticmethod
+    def forward(ctx, image_emb, profile_emb, margin):
+        a, p, u, v, iu, iv, S, n = _prep(image_emb, profile_emb, 1)
+        dev = a.device
+        row_sum = torch.empty(n, dtype=F32, device=dev)
+        col_sum = torch.empty(n, dtype=F32, device=dev)
+        loss = torch.empty((), dtype=F32, device=dev)
+        N.call('mpr_rank_fwd', S, float(margin), row_sum, col_sum, loss, n)
+        ctx.save_for_backward(a, p, u, v, iu, iv, row_sum, col_sum)
+        ctx.cfg = (n, float(margin))
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, p, u, v, iu, iv, row_sum, col_sum = ctx.saved_tensors
+        n, margin = ctx.cfg
+        gout = gout.contiguous().float()
+        G = torch.empty(1, n, n, dtype=F32, device=a.device)
+        N.call('mpr_rank_bwd', G, row_sum, col_sum, margin, gout, n)
+        # (gout is already folded into G: the normalisation backward gets a unit upstream gradient)
+        da, dp = _embedding_grads(ctx, G, None, a, p, u, v, iu, iv, n, 1, 0.0)
+        return da, dp, None
+
+
 class RankLoss(nn.Module):
     """Reference: src/coordination.py:115-135.  As in the reference, ``forward`` has no ``buckets``
     parameter, so ``MultiModel.training_step`` (which passes ``buckets``) raises TypeError for
-    ``method: rank`` -- kept on purpose.  No native kernel yet: direct calls raise."""
+    ``method: rank`` -- kept on purpose; direct calls run on the gfx950 kernels
+    (``mpr_rank_fwd`` / ``mpr_rank_bwd`` around the fp32 similarity GEMM)."""
 
     def __init__(self, margin: float) -> None:
         super().__init__()
         self.margin = margin
 
     def forward(self, image_emb: Tensor, profile_emb: Tensor) -> Tensor:
-        raise NotImplementedError('RankLoss: native gfx950 kernel not built yet (no torch fallback)')
+        return _RankFn.apply(image_emb, profile_emb, self.margin)

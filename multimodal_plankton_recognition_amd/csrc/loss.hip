@@ -400,5 +400,80 @@ int mpr_mse_add(const float* a, const float* b, float beta, float* loss, float* 
   MPR_LAUNCH_CHECK("finish_sum_kernel");
   return MPR_OK;
 }
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- RankLoss
+// src/coordination.py:115-135: S = u v^T with the diagonal negated; loss = ( mean relu(margin + column sums)
+// + mean relu(margin + row sums) ) / 2.   S: [n][n] raw cosines (left untouched: the sign flip is applied on the fly).
+__global__ __launch_bounds__(256) void rank_row_sums_kernel(const float* __restrict__ S, float* __restrict__ row_sum, int n) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* s = S + (size_t)row * n;
+  float a = 0.f;
+  for (int j = lane; j < n; j += 64) a += j == row ? -s[j] : s[j];
+  a = wave_sum(a);
+  if (lane == 0) row_sum[row] = a;
+}
+
+__global__ __launch_bounds__(256) void rank_col_sums_kernel(const float* __restrict__ S, float* __restrict__ col_sum, int n) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= n) return;
+  float a = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float v = S[(size_t)i * n + col];
+    a += i == col ? -v : v;
+  }
+  col_sum[col] = a;
+}
+
+__global__ __launch_bounds__(256) void rank_loss_kernel(const float* __restrict__ row_sum, const float* __restrict__ col_sum,
+                                                        float margin, float* __restrict__ loss, int n) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += (double)fmaxf(margin + row_sum[i], 0.f) + (double)fmaxf(margin + col_sum[i], 0.f);
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(red[0] / (2.0 * n));
+}
+
+// G[i][j] = gout / (2 n) * (1[margin + col_sum[j] > 0] + 1[margin + row_sum[i] > 0]) * (i == j ? -1 : 1)
+__global__ __launch_bounds__(256) void rank_grad_kernel(float* __restrict__ G, const float* __restrict__ row_sum,
+                                                        const float* __restrict__ col_sum, float margin,
+                                                        const float* __restrict__ gout, int n) {
+  const long long total = (long long)n * n;
+  const float g = (gout ? gout[0] : 1.f) / (2.f * n);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int i = (int)(idx / n), j = (int)(idx - (long long)i * n);
+    const float v = g * ((margin + col_sum[j] > 0.f ? 1.f : 0.f) + (margin + row_sum[i] > 0.f ? 1.f : 0.f));
+    G[idx] = i == j ? -v : v;
+  }
+}
+
+extern "C" {
+
+int mpr_rank_fwd(const float* S, float margin, float* row_sum, float* col_sum, float* loss, int n, void* stream) {
+  MPR_REQUIRE(S && row_sum && col_sum && loss && n > 0, "mpr_rank_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  rank_row_sums_kernel<<<(n + 3) / 4, 256, 0, st>>>(S, row_sum, n);
+  MPR_LAUNCH_CHECK("rank_row_sums_kernel");
+  rank_col_sums_kernel<<<(n + 255) / 256, 256, 0, st>>>(S, col_sum, n);
+  MPR_LAUNCH_CHECK("rank_col_sums_kernel");
+  rank_loss_kernel<<<1, 256, 0, st>>>(row_sum, col_sum, margin, loss, n);
+  MPR_LAUNCH_CHECK("rank_loss_kernel");
+  return MPR_OK;
+}
+
+int mpr_rank_bwd(float* G, const float* row_sum, const float* col_sum, float margin, const float* gout, int n, void* stream) {
+  MPR_REQUIRE(G && row_sum && col_sum && n > 0, "mpr_rank_bwd: bad arguments");
+  const long long total = (long long)n * n;
+  const int grid = (int)((total + 255) / 256 < LOSS_GRID ? (total + 255) / 256 : LOSS_GRID);
+  rank_grad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(G, row_sum, col_sum, margin, gout, n);
+  MPR_LAUNCH_CHECK("rank_grad_kernel");
+  return MPR_OK;
+}
 
 }  // extern "C"

@@ -120,14 +120,16 @@ class ProfileTransformer(nn.Module):
 
 
 class ProfileLSTM(nn.Module):
-    """Constructor / tokenize contract of src/profile_encoder.py:71-108 (low priority; no native
-    kernels yet, ``forward`` raises)."""
+    """LSTM profile encoder, reference src/profile_encoder.py:71-108: bias-free expand -> nn.LSTM -> output at
+    ``last_idx`` -> metadata concat -> dropout.  ``self.lstm`` is a parameter container (reference ``state_dict`` keys and
+    initialisation); the arithmetic runs on the gfx950 kernels in exact fp32 (``lstm.py``)."""
 
     def __init__(self, dim_in: int, dim_hidden: int, num_layers: int, dropout: float = 0.1,
                  metadata: bool = True) -> None:
         super().__init__()
         self.expand = nn.Linear(dim_in, dim_hidden, bias=False)
         self.lstm = nn.LSTM(dim_hidden, dim_hidden, num_layers, batch_first=True, dropout=dropout)
+        self.p_drop = float(dropout)
         self.dim_out = dim_hidden + metadata
         self.metadata = metadata
 
@@ -138,4 +140,11 @@ class ProfileLSTM(nn.Module):
         return {'profile': nn.utils.rnn.pad_sequence(list(profile), batch_first=True), 'last_idx': last}
 
     def forward(self, profile: Tensor, last_idx: Tensor, **kwargs) -> Tensor:
-        raise NotImplementedError('ProfileLSTM: native gfx950 path not built yet (no torch fallback)')
+        from .layers import TailFn, linear
+        from .lstm import lstm_stack
+        B, T, _ = profile.shape
+        d = self.expand.weight.shape[0]
+        x = linear(profile.reshape(B * T, -1).float().contiguous(), self.expand.weight).view(B, T, d)      # :99
+        feat = lstm_stack(self.lstm, x, last_idx, self.training)                                            # :100-101
+        meta = kwargs['profile_len'].contiguous() if self.metadata else None                               # :102-105
+        return TailFn.apply(feat, meta, profile.shape[1], self.p_drop if self.training else 0.0)
