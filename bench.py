@@ -125,6 +125,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the card: 512)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--card', default=CARD, help='model card (default: BASELINE C3; model_cards/vit_base_transformer_clip.yaml '
+                                                 'with --batch 128 is the per-GPU share of C5)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -139,7 +141,11 @@ def main():
     from multimodal_plankton_recognition_amd.model import MultiModel
     from multimodal_plankton_recognition_amd import distributed as D
 
-    card = yaml.safe_load(open(CARD))
+    card = yaml.safe_load(open(args.card))
+    c3 = os.path.abspath(args.card) == os.path.abspath(CARD)
+    from multimodal_plankton_recognition_amd import transformer as TF
+    TF.set_precision((card.get('trainer_args') or {}).get('precision'))      # transformer stacks only (16-mixed -> bf16 MFMA)
+    is_tf = 'num_head' in card['profile_encoder_args']
     T = card['target_size']
     B = args.batch or card['bs']
     if world > 1:
@@ -150,7 +156,7 @@ def main():
                        card['coordination_args'], card['optim_args']).to(dev).train()
     opt = model.configure_optimizers()
     stepper = D.DataParallelStep(model, opt, world) if world > 1 else None
-    batch = synthetic_batch(B, T, dev, 1234 + rank)
+    batch = synthetic_batch(B, T, dev, 1234 + rank, transformer=is_tf)
     batch['buckets'] = card['buckets']
 
     def one_step():
@@ -202,7 +208,7 @@ def main():
         algo_bytes = ig_bytes.value
         lib.mpr_prof_collect_bytes(1, ctypes.byref(ig_bytes))
         algo_bytes += ig_bytes.value
-        traffic = pmc_traffic('conv_igemm_dma_kernel')
+        traffic = pmc_traffic('conv_igemm_dma_kernel') if c3 else None      # (the committed PMC passes are C3's)
         achieved = ig_w / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         prof_steps = len(range(0, args.steps, 4))
@@ -211,8 +217,11 @@ def main():
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'C3: model_cards/resnet18_cnn_2_512_clip.yaml -- ResNet-18 (1x224x224) + ProfileCNN[2,2,2,2] '
-                                   '+ CLIP, D=512, full step (fwd+bwd+SGD nesterov), dropout 0.1',
+            'config': {'workload': ('C3: model_cards/resnet18_cnn_2_512_clip.yaml -- ResNet-18 (1x224x224) + ProfileCNN[2,2,2,2] '
+                                    '+ CLIP, D=512, full step (fwd+bwd+SGD nesterov), dropout 0.1') if c3 else
+                                   (f"{os.path.relpath(args.card, ROOT)} -- {card['image_encoder_args']['name']} + "
+                                    f"{'ProfileTransformer' if is_tf else 'profile encoder'} + "
+                                    f"{card['coordination_args']['method']}, transformer precision {TF._PRECISION[0]}, full step"),
                        'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'loss': round(loss_val, 5)},
@@ -227,12 +236,12 @@ def main():
                          'wgrad_kernel': {'name': 'conv_wgrad_win_kernel + conv_wgrad_dma_kernel',
                                           'achieved': round(w_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
                                           'launches': n_w, 'share_of_step_time': round(ms_w / prof_steps / ms_per_step, 3)},
-                         'alone': isolated_conv_rate(B, dev),
+                         'alone': isolated_conv_rate(B, dev) if c3 else None,
                          'note': 'achieved / avg_launch_us: event-timed on the launch stream INSIDE the timed steps, i.e. while '
                                  'the profile branch and the weight-gradient kernels run beside it on other streams; '
                                  '"alone" is the same kernel on the four ResNet-18 body shapes with the GPU to itself'},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and c3:
             # host share of a 1-GPU box is 16 cores (the node reports all of them): never oversubscribe
             threads = host_cores()
             out['cpu_baseline'] = cpu_baseline(card, T, threads)

@@ -290,6 +290,18 @@ int mpr_lstm_cell_bwd(const float* act, const float* c_prev /* NULL: zeros */, c
                       const float* dh_b /* may be NULL */, float* dc /* in: d c_t from step t+1, out: d c_{t-1} */,
                       float* dG /* [B][4d] */, int B, int d, void* stream);
 
+/* ---- few-shot evaluation: exact k-nearest neighbours + weighted vote (src/ann.py:6-34 as driven by
+ *      scripts/benchmark_cross.py:24-96; the reference's approximate NN-descent index is replaced by exact search) */
+int mpr_knn_sqnorm(const float* X, float* out /* [rows] */, int rows, int D, void* stream);
+/* dots [nq][ng] = X G^T (mpr_gemm_f32; overwritten); metric 0 euclidean, 1 cosine; idx int64 / dist fp32 [nq][k],
+ * ascending (distance, index); reported distances are recomputed directly from X and G (exact zeros) */
+int mpr_knn_select(float* dots, const float* q_sqnorm, const float* g_sqnorm, const float* X, const float* G, int metric,
+                   int nq, int ng, int k, int D, long long* idx, float* dist, void* stream);
+/* weights 1/dist (rows containing a zero distance: indicator of the zeros, src/ann.py:28-34), class of largest summed
+ * weight, ties to the smallest class id (sklearn weighted_mode) */
+int mpr_knn_vote(const long long* idx, const float* dist, const long long* labels /* [gallery] */, int nq, int m,
+                 long long* pred, void* stream);
+
 /* ---- optimiser, encoder tail, classifier loss --------------------------------------------------
  * optim.SGD over all parameters (src/model.py:147-148); metadata concat + dropout
  * (src/image_encoder.py:25-29, src/profile_encoder.py:234-240); CrossEntropyLoss + argmax
