@@ -202,7 +202,7 @@ int mpr_layernorm_bwd(const float* dy, const float* s, const float* gamma, const
 int mpr_masked_softmax_fwd(float* S /* [batch*heads*Tq][T], in place */, const void* key_padding_mask /* [batch][T] bytes or NULL */,
                            float scale, int batch, int heads, int Tq, int T, void* stream);
 int mpr_softmax_bwd(float* dP /* in place -> dS */, const float* P, float scale, int rows, int T, void* stream);
-/* act: 0 none, 1 exact GELU, 2 ReLU; optional inverted dropout (mask: 1 byte / element) */
+/* act: 0 none, 1 exact GELU, 2 ReLU, 3 SiLU, 4 sigmoid; optional inverted dropout (mask: 1 byte / element) */
 int mpr_bias_act_fwd(const float* x, const float* bias /* [D] or NULL */, int act, float p_drop, unsigned seed, float* y,
                      void* mask, long long n, int D, void* stream);
 int mpr_bias_act_bwd(const float* dy, const float* x, const float* bias, int act, float p_drop, const void* mask,
@@ -228,7 +228,7 @@ int mpr_tf_ln_bwd_workspace_floats(int rows, int D);
 int mpr_tf_ln_bwd(const void* dy16 /* may be NULL */, const float* dy32 /* may be NULL */, const float* s, const float* gamma,
                   const float* mean, const float* rstd, const float* dskip /* may be NULL */, float* ds, float* dgamma,
                   float* dbeta, float* workspace, int accumulate, int rows, int D, void* stream);
-/* y = drop(act(x + bias)), bf16 -> bf16 [rows][D], D % 8 == 0; act: 0 none, 1 exact GELU, 2 ReLU */
+/* y = drop(act(x + bias)), bf16 -> bf16 [rows][D], D % 8 == 0; act: 0 none, 1 exact GELU, 2 ReLU, 3 SiLU, 4 sigmoid */
 int mpr_tf_bias_act_fwd(const void* x, const float* bias /* may be NULL */, int act, float p_drop, unsigned seed, void* y,
                         long long rows, int D, void* stream);
 /* backward elementwise passes fused with the column sums of a bias gradient (added into dbias):
@@ -289,6 +289,20 @@ int mpr_lstm_cell_fwd(const float* G /* [B][4d] x W_ih^T + b_ih + h_prev W_hh^T 
 int mpr_lstm_cell_bwd(const float* act, const float* c_prev /* NULL: zeros */, const float* c, const float* dh_a,
                       const float* dh_b /* may be NULL */, float* dc /* in: d c_t from step t+1, out: d c_{t-1} */,
                       float* dG /* [B][4d] */, int B, int d, void* stream);
+
+/* ---- EfficientNet pieces (timm efficientnet_b0 behind src/image_encoder.py:16,24; model_cards/example_multi.yaml:9):
+ *      depthwise convolution (nn.Conv2d(groups=C)) on channels-last bf16 with the torch [C][1][R][S] fp32 filter, and the
+ *      squeeze-excite gate; 1x1 convs run on mpr_conv_*, BatchNorm on mpr_bn_*, SiLU on mpr_tf_bias_act_fwd / mpr_tf_ew_bwd */
+int mpr_dwconv_fwd(const void* x, const float* w, void* y, int B, int H, int W, int C, int R, int S, int sh, int sw, int ph,
+                   int pw, void* stream);
+int mpr_dwconv_dgrad(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int R, int S, int sh, int sw,
+                     int ph, int pw, void* stream);
+long long mpr_dwconv_wgrad_workspace_floats(int B, int P, int Q, int C, int R, int S);
+int mpr_dwconv_wgrad(const void* x, const void* dy, float* dw /* [C][1][R][S] */, float* workspace, int accumulate, int B,
+                     int H, int W, int C, int R, int S, int sh, int sw, int ph, int pw, void* stream);
+int mpr_se_scale(const void* x /* [B][L][C] bf16 */, const float* gate /* [B][C] */, void* y, int B, int L, int C,
+                 void* stream);
+int mpr_se_dgate(const void* x, const void* dy, float* dgate /* [B][C] = sum_l dy * x */, int B, int L, int C, void* stream);
 
 /* ---- few-shot evaluation: exact k-nearest neighbours + weighted vote (src/ann.py:6-34 as driven by
  *      scripts/benchmark_cross.py:24-96; the reference's approximate NN-descent index is replaced by exact search) */

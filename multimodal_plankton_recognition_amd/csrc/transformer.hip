@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restri
     float v = x[i] + (bias ? bias[i % D] : 0.f);
     if (act == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     else if (act == 2) v = fmaxf(v, 0.f);
+    else if (act == 3) v = v / (1.f + expf(-v));          // SiLU
+    else if (act == 4) v = 1.f / (1.f + expf(-v));        // sigmoid
     if (p_drop > 0.f) {
       const uint32_t h = tf_mix32(tf_mix32((uint32_t)i ^ seed) + 0x9e3779b9U * (seed | 1u) + (uint32_t)(i >> 32));
       const bool keep = (float)(h >> 8) * (1.f / 16777216.f) >= p_drop;
@@ -160,8 +162,11 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
         const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
         const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
         g *= cdf + v * pdf;
-      } else {
+      } else if (act == 2) {
         g = v > 0.f ? g : 0.f;
+      } else {
+        const float sg = 1.f / (1.f + expf(-v));
+        g *= act == 3 ? sg * (1.f + v * (1.f - sg)) : sg * (1.f - sg);
       }
     }
     dx[i] = g;
@@ -258,7 +263,7 @@ int mpr_softmax_bwd(float* dP, const float* P, float scale, int rows, int T, voi
 
 int mpr_bias_act_fwd(const float* x, const float* bias, int act, float p_drop, unsigned seed, float* y, void* mask,
                      long long n, int D, void* stream) {
-  MPR_REQUIRE(x && y && (p_drop == 0.f || mask) && act >= 0 && act <= 2, "mpr_bias_act_fwd: bad arguments");
+  MPR_REQUIRE(x && y && (p_drop == 0.f || mask) && act >= 0 && act <= 4, "mpr_bias_act_fwd: bad arguments");
   bias_act_fwd_kernel<<<tf_grid(n), 256, 0, (hipStream_t)stream>>>(x, bias, act, p_drop, seed, y, (unsigned char*)mask, n, D);
   MPR_LAUNCH_CHECK("bias_act_fwd_kernel");
   return MPR_OK;

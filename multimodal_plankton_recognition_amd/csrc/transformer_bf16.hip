@@ -52,6 +52,8 @@ __device__ __forceinline__ float act_fwd(float v, int act) {
     return v * cdf;
   }
   if (act == 2) return fmaxf(v, 0.f);
+  if (act == 3) return v / (1.f + __expf(-v));            // SiLU
+  if (act == 4) return 1.f / (1.f + __expf(-v));          // sigmoid
   return v;
 }
 __device__ __forceinline__ float act_grad(float v, int act) {
@@ -61,6 +63,10 @@ __device__ __forceinline__ float act_grad(float v, int act) {
     return fmaf(v * 0.3989422804014327f, g, cdf);
   }
   if (act == 2) return v > 0.f ? 1.f : 0.f;
+  if (act == 3 || act == 4) {
+    const float sg = 1.f / (1.f + __expf(-v));
+    return act == 3 ? sg * fmaf(v, 1.f - sg, 1.f) : sg * (1.f - sg);
+  }
   return 1.f;
 }
 
@@ -797,7 +803,7 @@ int mpr_tf_ln_bwd(const void* dy16, const float* dy32, const float* s, const flo
 
 int mpr_tf_bias_act_fwd(const void* x, const float* bias, int act, float p_drop, unsigned seed, void* y, long long rows, int D,
                         void* stream) {
-  MPR_REQUIRE(x && y && rows > 0 && D > 0 && D % 8 == 0 && act >= 0 && act <= 2, "mpr_tf_bias_act_fwd: bad arguments (D=%d)", D);
+  MPR_REQUIRE(x && y && rows > 0 && D > 0 && D % 8 == 0 && act >= 0 && act <= 4, "mpr_tf_bias_act_fwd: bad arguments (D=%d)", D);
   const long long ng = rows * D / 8;
   tf_bias_act_fwd_kernel<<<tb_grid(ng), 256, 0, (hipStream_t)stream>>>((const uint4*)x, bias, act, p_drop, seed, (uint4*)y, ng, D);
   MPR_LAUNCH_CHECK("tf_bias_act_fwd_kernel");

@@ -147,9 +147,12 @@ def create_backbone(name: str, in_chans: int = 1):
     if name in _VITS:
         dim, depth, heads, patch = _VITS[name]
         return ViTBackbone(dim, depth, heads, patch, 224, in_chans)
+    if name == 'efficientnet_b0':
+        from .efficientnet import EfficientNetBackbone
+        return EfficientNetBackbone(in_chans)
     raise NotImplementedError(
         f"image backbone '{name}': BasicBlock ResNets ({', '.join(k for k, v in _RESNETS.items() if v)}) and ViTs "
-        f"({', '.join(_VITS)}) have native gfx950 kernels so far")
+        f"({', '.join(_VITS)}) and efficientnet_b0 have native gfx950 kernels so far")
 
 
 class ImageEncoder(nn.Module):

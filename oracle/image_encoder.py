@@ -6,8 +6,8 @@ which is absent from this image and from /root/reference; the reference holds
 no test or golden vector at that boundary.  The topology below is the published
 torchvision/timm ResNet-18 (BasicBlock [2,2,2,2], 7x7/2 stem, 3x3/2 max-pool,
 global average pool, identity head for num_classes=0) and timm's
-VisionTransformer (pre-norm, LN eps 1e-6, qkv bias, exact GELU, CLS pooling),
-with timm's state_dict key names.  ImageEncoder's own arithmetic (metadata
+VisionTransformer (pre-norm, LN eps 1e-6, qkv bias, exact GELU, CLS pooling)
+and timm's EfficientNet-B0 (MBConv stages, SE, SiLU), with timm's state_dict key names.  ImageEncoder's own arithmetic (metadata
 concat, image_encoder.py:23-29) IS restated from the reference source.
 """
 import math
@@ -74,11 +74,54 @@ def vit_features(sd, image, num_heads, depth, patch=16, prefix=''):
     return x[:, 0]
 
 
+EFFICIENTNET_B0 = ((1, 3, 1, 1, 16), (2, 3, 2, 6, 24), (2, 5, 2, 6, 40), (3, 3, 2, 6, 80), (3, 5, 1, 6, 112),
+                   (4, 5, 2, 6, 192), (1, 3, 1, 6, 320))        # (repeats, kernel, stride, expansion, out channels)
+
+
+def _se(sd, p, x):
+    """timm SqueezeExcite: x * sigmoid(conv_expand(silu(conv_reduce(mean_hw x))))."""
+    s = x.mean((2, 3), keepdim=True)
+    s = F.silu(F.conv2d(s, sd[p + 'conv_reduce.weight'], sd[p + 'conv_reduce.bias']))
+    s = F.conv2d(s, sd[p + 'conv_expand.weight'], sd[p + 'conv_expand.bias'])
+    return x * torch.sigmoid(s)
+
+
+def efficientnet_features(sd, image, arch=EFFICIENTNET_B0, train=False, prefix=''):
+    """timm EfficientNet (efficientnet_b0 family: symmetric padding, BN eps 1e-5, SiLU, SE on 1/4 of the block input
+    width, no drop-path), pooled features [B, 1280].  Topology from the published definition; parity unpinned."""
+    x = r(F.conv2d(r(image), sd[prefix + 'conv_stem.weight'], None, 2, 1))
+    x = r(F.silu(r(_bn2d(sd, prefix + 'bn1', x, train))))
+    for si, (reps, k, stride, exp, cout) in enumerate(arch):
+        for bi in range(reps):
+            p = f'{prefix}blocks.{si}.{bi}.'
+            s = stride if bi == 0 else 1
+            inp = x
+            if exp != 1:
+                x = r(F.conv2d(x, r(sd[p + 'conv_pw.weight'])))
+                x = r(F.silu(r(_bn2d(sd, p + 'bn1', x, train))))
+                dw_bn = 'bn2'
+            else:
+                dw_bn = 'bn1'
+            w = sd[p + 'conv_dw.weight']
+            x = r(F.conv2d(x, w, None, s, k // 2, groups=w.shape[0]))
+            x = r(F.silu(r(_bn2d(sd, p + dw_bn, x, train))))
+            x = r(_se(sd, p + 'se.', x))
+            last, last_bn = ('conv_pw', 'bn2') if exp == 1 else ('conv_pwl', 'bn3')
+            x = r(F.conv2d(x, r(sd[p + last + '.weight'])))
+            x = _bn2d(sd, p + last_bn, x, train)
+            x = r(x + inp) if (s == 1 and inp.shape[1] == x.shape[1]) else r(x)
+    x = r(F.conv2d(x, r(sd[prefix + 'conv_head.weight'])))
+    x = r(F.silu(r(_bn2d(sd, prefix + 'bn2', x, train))))
+    return x.mean(dim=(2, 3))
+
+
 def image_encoder_forward(sd, image, image_shape, arch='resnet18', train=False, metadata=True,
                           prefix='backbone.', **arch_kw):
     """ImageEncoder.forward, image_encoder.py:23-29: features ++ (orig H, W) / tensor H."""
     if arch.startswith('resnet'):
         x = resnet_features(sd, image, arch_kw.get('blocks', (2, 2, 2, 2)), train, prefix)
+    elif arch.startswith('efficientnet'):
+        x = efficientnet_features(sd, image, arch_kw.get('arch', EFFICIENTNET_B0), train, prefix)
     else:
         x = vit_features(sd, image, arch_kw['num_heads'], arch_kw['depth'], arch_kw.get('patch', 16), prefix)
     if metadata:
