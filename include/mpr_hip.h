@@ -293,16 +293,18 @@ int mpr_lstm_cell_bwd(const float* act, const float* c_prev /* NULL: zeros */, c
 /* ---- EfficientNet pieces (timm efficientnet_b0 behind src/image_encoder.py:16,24; model_cards/example_multi.yaml:9):
  *      depthwise convolution (nn.Conv2d(groups=C)) on channels-last bf16 with the torch [C][1][R][S] fp32 filter, and the
  *      squeeze-excite gate; 1x1 convs run on mpr_conv_*, BatchNorm on mpr_bn_*, SiLU on mpr_tf_bias_act_fwd / mpr_tf_ew_bwd */
-int mpr_dwconv_fwd(const void* x, const float* w, void* y, int B, int H, int W, int C, int R, int S, int sh, int sw, int ph,
-                   int pw, void* stream);
-int mpr_dwconv_dgrad(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int R, int S, int sh, int sw,
-                     int ph, int pw, void* stream);
+/* wt: C*R*S floats of scratch (the filter is re-laid tap-major there first) */
+int mpr_dwconv_fwd(const void* x, const float* w, float* wt, void* y, int B, int H, int W, int C, int R, int S, int sh, int sw,
+                   int ph, int pw, void* stream);
+int mpr_dwconv_dgrad(const void* dy, const float* w, float* wt, void* dx, int B, int H, int W, int C, int R, int S, int sh,
+                     int sw, int ph, int pw, void* stream);
 long long mpr_dwconv_wgrad_workspace_floats(int B, int P, int Q, int C, int R, int S);
 int mpr_dwconv_wgrad(const void* x, const void* dy, float* dw /* [C][1][R][S] */, float* workspace, int accumulate, int B,
                      int H, int W, int C, int R, int S, int sh, int sw, int ph, int pw, void* stream);
 int mpr_se_scale(const void* x /* [B][L][C] bf16 */, const float* gate /* [B][C] */, void* y, int B, int L, int C,
                  void* stream);
 int mpr_se_dgate(const void* x, const void* dy, float* dgate /* [B][C] = sum_l dy * x */, int B, int L, int C, void* stream);
+int mpr_se_pool(const void* x, float* pooled /* [B][C] = mean_l x */, int B, int L, int C, void* stream);
 
 /* ---- few-shot evaluation: exact k-nearest neighbours + weighted vote (src/ann.py:6-34 as driven by
  *      scripts/benchmark_cross.py:24-96; the reference's approximate NN-descent index is replaced by exact search) */

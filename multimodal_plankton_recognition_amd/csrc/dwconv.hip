@@ -12,10 +12,18 @@ struct DwGeom {
   int B, H, W, C, P, Q, R, S, sh, sw, ph, pw;
 };
 
-// y[b][p][q][c] = sum_{r,s} x[b][p*sh-ph+r][q*sw-pw+s][c] * w[c][r][s]       (w: torch [C][1][R][S] fp32)
+// wt[tap][c] = w[c][tap]    (torch [C][1][R][S] -> tap-major: a thread's 8 channels of one tap are two float4)
+__global__ __launch_bounds__(256) void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int C, int RS) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * RS) return;
+  const int tap = i / C, c = i - tap * C;
+  wt[i] = w[(size_t)c * RS + tap];
+}
+
+// y[b][p][q][c] = sum_{r,s} x[b][p*sh-ph+r][q*sw-pw+s][c] * wt[r*S+s][c]
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const uint4* __restrict__ x, const float* __restrict__ w,
                                                      uint4* __restrict__ y, const DwGeom g) {
-  const int G = g.C / 8, RS = g.R * g.S;
+  const int G = g.C / 8;
   const long long total = (long long)g.B * g.P * g.Q * G;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int cg = (int)(idx % G);
@@ -34,9 +42,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const uint4* __restrict__ x
         if (ww < 0 || ww >= g.W) continue;
         float f[8];
         unpack8(x[((size_t)(b * g.H + h) * g.W + ww) * G + cg], f);
-        const float* wp = w + (size_t)cg * 8 * RS + r * g.S + s;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(f[e], wp[e * RS], acc[e]);
+        const float4* wp = reinterpret_cast<const float4*>(w + (size_t)(r * g.S + s) * g.C + cg * 8);
+        const float4 w0 = wp[0], w1 = wp[1];
+        acc[0] = fmaf(f[0], w0.x, acc[0]); acc[1] = fmaf(f[1], w0.y, acc[1]); acc[2] = fmaf(f[2], w0.z, acc[2]);
+        acc[3] = fmaf(f[3], w0.w, acc[3]); acc[4] = fmaf(f[4], w1.x, acc[4]); acc[5] = fmaf(f[5], w1.y, acc[5]);
+        acc[6] = fmaf(f[6], w1.z, acc[6]); acc[7] = fmaf(f[7], w1.w, acc[7]);
       }
     }
     y[idx] = pack8(acc);
@@ -46,7 +56,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const uint4* __restrict__ x
 // dx[b][h][w][c] = sum_{r,s : (h+ph-r) % sh == 0, ...} dy[b][(h+ph-r)/sh][(w+pw-s)/sw][c] * w[c][r][s]
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const uint4* __restrict__ dy, const float* __restrict__ w,
                                                        uint4* __restrict__ dx, const DwGeom g) {
-  const int G = g.C / 8, RS = g.R * g.S;
+  const int G = g.C / 8;
   const long long total = (long long)g.B * g.H * g.W * G;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int cg = (int)(idx % G);
@@ -69,9 +79,11 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const uint4* __restrict__
         if (q >= g.Q) continue;
         float f[8];
         unpack8(dy[((size_t)(b * g.P + p) * g.Q + q) * G + cg], f);
-        const float* wp = w + (size_t)cg * 8 * RS + r * g.S + s;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(f[e], wp[e * RS], acc[e]);
+        const float4* wp = reinterpret_cast<const float4*>(w + (size_t)(r * g.S + s) * g.C + cg * 8);
+        const float4 w0 = wp[0], w1 = wp[1];
+        acc[0] = fmaf(f[0], w0.x, acc[0]); acc[1] = fmaf(f[1], w0.y, acc[1]); acc[2] = fmaf(f[2], w0.z, acc[2]);
+        acc[3] = fmaf(f[3], w0.w, acc[3]); acc[4] = fmaf(f[4], w1.x, acc[4]); acc[5] = fmaf(f[5], w1.y, acc[5]);
+        acc[6] = fmaf(f[6], w1.z, acc[6]); acc[7] = fmaf(f[7], w1.w, acc[7]);
       }
     }
     dx[idx] = pack8(acc);
@@ -110,16 +122,18 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const uint4* __restrict__
   *reinterpret_cast<float4*>(out + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
-// dw[c][r][s] (+)= sum_slab part[slab][tap][c]
+// dw[c][r][s] += sum_slab part[slab][tap][c]   (slabs split over gridDim.y, a few-way atomic per element)
 __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nslabs,
-                                                              int RS, int C, int accumulate) {
+                                                              int RS, int C) {
   const int i = blockIdx.x * 256 + threadIdx.x;       // = tap * C + c
   if (i >= RS * C) return;
-  double a = 0.0;
-  for (int sl = 0; sl < nslabs; ++sl) a += (double)part[(size_t)sl * RS * C + i];
+  const int per = (nslabs + gridDim.y - 1) / gridDim.y;
+  int s0 = blockIdx.y * per, s1 = s0 + per;
+  if (s1 > nslabs) s1 = nslabs;
+  float a = 0.f;
+  for (int sl = s0; sl < s1; ++sl) a += part[(size_t)sl * RS * C + i];
   const int tap = i / C, c = i - tap * C;
-  float* o = dw + (size_t)c * RS + tap;
-  *o = accumulate ? *o + (float)a : (float)a;
+  atomicAdd(dw + (size_t)c * RS + tap, a);
 }
 
 // y = x * gate[b][c]     x, y: [B][L][C] bf16, gate: [B][C] fp32
@@ -138,33 +152,45 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const uint4* __restrict__
   }
 }
 
-// dgate[b][c] = sum_l dy[b][l][c] * x[b][l][c];  block = 64 channel groups x 4 row lanes of one image
-__global__ __launch_bounds__(256) void se_dgate_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy,
-                                                       float* __restrict__ dgate, int L, int C) {
-  __shared__ float red[3][8][64];
-  const int G = C / 8, cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int cg = blockIdx.x * 64 + cl, b = blockIdx.y;
+// Per-image channel sums over the L pixels: out[b][c] = scale * sum_l x[b][l][c] (* dy[b][l][c] when MUL): the SE squeeze
+// (mean) and the gate gradient.  Block = Gp channel groups (power of two >= C/8, at most 256) x 256/Gp row lanes of ONE
+// image, so that narrow-and-large maps (C = 32 at 112 x 112) still fill the block; lanes reduced through LDS.
+template <bool MUL>
+__global__ __launch_bounds__(256) void se_sum_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy,
+                                                     float* __restrict__ out, int L, int C, int Gp, float scale) {
+  __shared__ float red[256][9];
+  const int G = C / 8, nl = 256 / Gp;
+  const int cl = threadIdx.x % Gp, rl = threadIdx.x / Gp;
+  const int cg = blockIdx.x * Gp + cl, b = blockIdx.y;
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   if (cg < G) {
-    for (int l = rl; l < L; l += 4) {
-      float a[8], d[8];
+    for (int l = rl; l < L; l += nl) {
+      float a[8];
       const size_t o = ((size_t)b * L + l) * G + cg;
       unpack8(x[o], a);
-      unpack8(dy[o], d);
+      if (MUL) {
+        float d[8];
+        unpack8(dy[o], d);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(a[e], d[e], acc[e]);
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(a[e], d[e], acc[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += a[e];
+      }
     }
   }
-  if (rl > 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[rl - 1][e][cl] = acc[e];
-  }
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
   __syncthreads();
   if (rl == 0 && cg < G) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dgate[(size_t)b * C + cg * 8 + e] = acc[e] + red[0][e][cl] + red[1][e][cl] + red[2][e][cl];
+    for (int e = 0; e < 8; ++e) {
+      float a = 0.f;
+      for (int l = 0; l < nl; ++l) a += red[l * Gp + cl][e];
+      out[(size_t)b * C + cg * 8 + e] = a * scale;
+    }
   }
 }
 
@@ -180,31 +206,37 @@ static inline bool dw_geom(DwGeom* g, int B, int H, int W, int C, int R, int S, 
   return B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && g->P > 0 && g->Q > 0;
 }
 
-#define DW_PIX_PER_SLAB 256
+static inline int dw_pix_per_slab(long long npix) {      // at most 512 slabs of at least 256 pixels
+  long long p = (npix + 511) / 512;
+  return (int)(p < 256 ? 256 : p);
+}
 
 extern "C" {
 
-int mpr_dwconv_fwd(const void* x, const float* w, void* y, int B, int H, int W, int C, int R, int S, int sh, int sw, int ph,
-                   int pw, void* stream) {
+int mpr_dwconv_fwd(const void* x, const float* w, float* wt, void* y, int B, int H, int W, int C, int R, int S, int sh, int sw,
+                   int ph, int pw, void* stream) {
   DwGeom g;
-  MPR_REQUIRE(x && w && y && dw_geom(&g, B, H, W, C, R, S, sh, sw, ph, pw), "mpr_dwconv_fwd: bad arguments (C %% 8 == 0 needed, C=%d)", C);
-  dw_fwd_kernel<<<dw_grid((long long)B * g.P * g.Q * (C / 8)), 256, 0, (hipStream_t)stream>>>((const uint4*)x, w, (uint4*)y, g);
+  MPR_REQUIRE(x && w && wt && y && dw_geom(&g, B, H, W, C, R, S, sh, sw, ph, pw), "mpr_dwconv_fwd: bad arguments (C %% 8 == 0 needed, C=%d)", C);
+  dw_pack_kernel<<<ceil_div(C * R * S, 256), 256, 0, (hipStream_t)stream>>>(w, wt, C, R * S);
+  dw_fwd_kernel<<<dw_grid((long long)B * g.P * g.Q * (C / 8)), 256, 0, (hipStream_t)stream>>>((const uint4*)x, wt, (uint4*)y, g);
   MPR_LAUNCH_CHECK("dw_fwd_kernel");
   return MPR_OK;
 }
 
-int mpr_dwconv_dgrad(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int R, int S, int sh, int sw, int ph,
-                     int pw, void* stream) {
+int mpr_dwconv_dgrad(const void* dy, const float* w, float* wt, void* dx, int B, int H, int W, int C, int R, int S, int sh, int sw,
+                     int ph, int pw, void* stream) {
   DwGeom g;
-  MPR_REQUIRE(dy && w && dx && dw_geom(&g, B, H, W, C, R, S, sh, sw, ph, pw), "mpr_dwconv_dgrad: bad arguments");
-  dw_dgrad_kernel<<<dw_grid((long long)B * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>((const uint4*)dy, w, (uint4*)dx, g);
+  MPR_REQUIRE(dy && w && wt && dx && dw_geom(&g, B, H, W, C, R, S, sh, sw, ph, pw), "mpr_dwconv_dgrad: bad arguments");
+  dw_pack_kernel<<<ceil_div(C * R * S, 256), 256, 0, (hipStream_t)stream>>>(w, wt, C, R * S);
+  dw_dgrad_kernel<<<dw_grid((long long)B * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>((const uint4*)dy, wt, (uint4*)dx, g);
   MPR_LAUNCH_CHECK("dw_dgrad_kernel");
   return MPR_OK;
 }
 
 long long mpr_dwconv_wgrad_workspace_floats(int B, int P, int Q, int C, int R, int S) {
-  const long long slabs = ((long long)B * P * Q + DW_PIX_PER_SLAB - 1) / DW_PIX_PER_SLAB;
-  return slabs * R * S * C;
+  const long long npix = (long long)B * P * Q;
+  const int pps = dw_pix_per_slab(npix);
+  return (npix + pps - 1) / pps * R * S * C;
 }
 
 int mpr_dwconv_wgrad(const void* x, const void* dy, float* dw, float* workspace, int accumulate, int B, int H, int W, int C,
@@ -212,13 +244,13 @@ int mpr_dwconv_wgrad(const void* x, const void* dy, float* dw, float* workspace,
   DwGeom g;
   MPR_REQUIRE(x && dy && dw && workspace && dw_geom(&g, B, H, W, C, R, S, sh, sw, ph, pw), "mpr_dwconv_wgrad: bad arguments");
   const long long npix = (long long)B * g.P * g.Q;
-  const int slabs = (int)((npix + DW_PIX_PER_SLAB - 1) / DW_PIX_PER_SLAB);
-  MPR_REQUIRE(slabs <= 65535, "mpr_dwconv_wgrad: too many pixel slabs (%d)", slabs);
+  const int pps = dw_pix_per_slab(npix);
+  const int slabs = (int)((npix + pps - 1) / pps);
   hipStream_t st = (hipStream_t)stream;
-  dw_wgrad_kernel<<<dim3(ceil_div(R * S * (C / 8), 256), slabs), 256, 0, st>>>((const uint4*)x, (const uint4*)dy, workspace, g,
-                                                                               DW_PIX_PER_SLAB);
+  dw_wgrad_kernel<<<dim3(ceil_div(R * S * (C / 8), 256), slabs), 256, 0, st>>>((const uint4*)x, (const uint4*)dy, workspace, g, pps);
   MPR_LAUNCH_CHECK("dw_wgrad_kernel");
-  dw_wgrad_reduce_kernel<<<ceil_div(R * S * C, 256), 256, 0, st>>>(workspace, dw, slabs, R * S, C, accumulate);
+  if (!accumulate) MPR_HIP(hipMemsetAsync(dw, 0, sizeof(float) * R * S * C, st));
+  dw_wgrad_reduce_kernel<<<dim3(ceil_div(R * S * C, 256), slabs >= 32 ? 16 : 1), 256, 0, st>>>(workspace, dw, slabs, R * S, C);
   MPR_LAUNCH_CHECK("dw_wgrad_reduce_kernel");
   return MPR_OK;
 }
@@ -230,10 +262,27 @@ int mpr_se_scale(const void* x, const float* gate, void* y, int B, int L, int C,
   return MPR_OK;
 }
 
+static inline int se_gp(int C) {
+  int gp = 1;
+  while (gp < C / 8 && gp < 256) gp <<= 1;
+  return gp;
+}
+
 int mpr_se_dgate(const void* x, const void* dy, float* dgate, int B, int L, int C, void* stream) {
   MPR_REQUIRE(x && dy && dgate && B > 0 && B <= 65535 && L > 0 && C > 0 && C % 8 == 0, "mpr_se_dgate: bad arguments");
-  se_dgate_kernel<<<dim3(ceil_div(C / 8, 64), B), 256, 0, (hipStream_t)stream>>>((const uint4*)x, (const uint4*)dy, dgate, L, C);
-  MPR_LAUNCH_CHECK("se_dgate_kernel");
+  const int gp = se_gp(C);
+  se_sum_kernel<true><<<dim3(ceil_div(C / 8, gp), B), 256, 0, (hipStream_t)stream>>>((const uint4*)x, (const uint4*)dy, dgate, L, C,
+                                                                                     gp, 1.f);
+  MPR_LAUNCH_CHECK("se_sum_kernel");
+  return MPR_OK;
+}
+
+int mpr_se_pool(const void* x, float* pooled, int B, int L, int C, void* stream) {
+  MPR_REQUIRE(x && pooled && B > 0 && B <= 65535 && L > 0 && C > 0 && C % 8 == 0, "mpr_se_pool: bad arguments");
+  const int gp = se_gp(C);
+  se_sum_kernel<false><<<dim3(ceil_div(C / 8, gp), B), 256, 0, (hipStream_t)stream>>>((const uint4*)x, nullptr, pooled, L, C, gp,
+                                                                                      1.f / (float)L);
+  MPR_LAUNCH_CHECK("se_sum_kernel");
   return MPR_OK;
 }
 

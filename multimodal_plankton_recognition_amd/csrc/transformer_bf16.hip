@@ -317,6 +317,36 @@ struct EwBwdParams {
   int rows, D, rows_per_slab;
 };
 
+// the same passes without column sums (no bias behind the activation: SiLU of the conv stacks) -- flat over 16-byte groups, so
+// that narrow tensors (C = 32) keep every lane busy
+template <int MODE>
+__global__ __launch_bounds__(256) void tf_ew_bwd_flat_kernel(const EwBwdParams p) {
+  const long long ngroups = (long long)p.rows * p.D / 8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ngroups; i += (long long)gridDim.x * 256) {
+    const size_t o = (size_t)i * 8;
+    float g[8];
+    if (MODE == 2) {
+      const float4 a = *reinterpret_cast<const float4*>((const float*)p.dy + o);
+      const float4 b = *reinterpret_cast<const float4*>((const float*)p.dy + o + 4);
+      g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+    } else {
+      unpack8(*reinterpret_cast<const uint4*>((const uint16_t*)p.dy + o), g);
+    }
+    if (p.p_drop > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = tb_keep(p.seed, o + e, p.p_drop) ? g[e] / (1.f - p.p_drop) : 0.f;
+    }
+    if (MODE == 1 && p.act != 0) {
+      float xv[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.x + o), xv);
+      const int col = (int)(o % p.D);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] *= act_grad(xv[e] + (p.bias ? p.bias[col + e] : 0.f), p.act);
+    }
+    *reinterpret_cast<uint4*>(p.dx + o) = pack8(g);
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void tf_ew_bwd_kernel(const EwBwdParams p) {
   __shared__ float red[3][8][64];
@@ -838,6 +868,13 @@ int mpr_tf_ew_bwd(int mode, const void* dy, const void* x, const float* bias, in
   EwBwdParams p = {dy, (const uint16_t*)x, bias, act, p_drop, seed, (uint16_t*)dx, dbias ? workspace : nullptr, rows, D, rps};
   const dim3 grid(gx, slabs);
   hipStream_t st = (hipStream_t)stream;
+  if (!dbias && mode != 0) {
+    const unsigned fg = tb_grid((long long)rows * D / 8);
+    if (mode == 1) tf_ew_bwd_flat_kernel<1><<<fg, 256, 0, st>>>(p);
+    else tf_ew_bwd_flat_kernel<2><<<fg, 256, 0, st>>>(p);
+    MPR_LAUNCH_CHECK("tf_ew_bwd_flat_kernel");
+    return MPR_OK;
+  }
   if (mode == 0) tf_ew_bwd_kernel<0><<<grid, 256, 0, st>>>(p);
   else if (mode == 1) tf_ew_bwd_kernel<1><<<grid, 256, 0, st>>>(p);
   else tf_ew_bwd_kernel<2><<<grid, 256, 0, st>>>(p);

@@ -34,13 +34,13 @@ def dwconv_fwd(x, w, g):
     B, H, W, C = x.shape
     P, Q = g.out_hw(H, W)
     y = torch.empty(B, P, Q, C, dtype=BF16, device=x.device)
-    N.call('mpr_dwconv_fwd', x, w.detach(), y, *_dw_args(x, g))
+    N.call('mpr_dwconv_fwd', x, w.detach(), torch.empty(w.numel(), dtype=F32, device=x.device), y, *_dw_args(x, g))
     return y
 
 
 def dwconv_dgrad(dy, w, g, x_shape):
     dx = torch.empty(x_shape, dtype=BF16, device=dy.device)
-    N.call('mpr_dwconv_dgrad', dy, w.detach(), dx, *_dw_args(dx, g))
+    N.call('mpr_dwconv_dgrad', dy, w.detach(), torch.empty(w.numel(), dtype=F32, device=dy.device), dx, *_dw_args(dx, g))
     return dx
 
 
@@ -139,7 +139,8 @@ class SqueezeExciteFn(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2):
         B, H, W, C = x.shape
         rd = w1.shape[0]
-        pooled, _ = ops.global_pool_fwd(x, 'avg')                                     # [B, C] fp32
+        pooled = torch.empty(B, C, dtype=F32, device=x.device)
+        N.call('mpr_se_pool', x, pooled, B, H * W, C)                                 # squeeze: mean over pixels
         z1 = ops.gemm(pooled, w1.detach().view(rd, C), trans_b=True)                  # pre-activation (bias added in act)
         r = _act32(z1, b1, _SILU)
         z2 = ops.gemm(r, w2.detach().view(C, rd), trans_b=True)
