@@ -90,36 +90,65 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const uint4* __restrict__
   }
 }
 
-// partial weight gradients of one slab of output pixels: part[slab][tap][C]; thread = (tap, channel group)
+// partial weight gradients of one slab of output pixels and ONE filter row r = blockIdx.z: part[slab][tap][C].
+// Block = Gp channel groups (power of two >= C/8, <= 256) x 256/Gp pixel lanes; a thread keeps the S <= 5 taps of the row for
+// its 8 channels in registers (dy loaded once per pixel, x once per tap), lanes reduced through LDS.
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy,
-                                                       float* __restrict__ part, const DwGeom g, int pix_per_slab) {
-  const int G = g.C / 8, RS = g.R * g.S;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= RS * G) return;
-  const int tap = t / G, cg = t - tap * G;
-  const int r = tap / g.S, s = tap - r * g.S;
+                                                       float* __restrict__ part, const DwGeom g, int pix_per_slab, int Gp) {
+  __shared__ float red[256][41];
+  const int G = g.C / 8, RS = g.R * g.S, nl = 256 / Gp;
+  const int cl = threadIdx.x % Gp, rl = threadIdx.x / Gp;
+  const int cg = blockIdx.x * Gp + cl, r = blockIdx.z;
   const long long npix = (long long)g.B * g.P * g.Q;
   const long long p0 = (long long)blockIdx.y * pix_per_slab;
   long long p1 = p0 + pix_per_slab;
   if (p1 > npix) p1 = npix;
-  float acc[8];
+  float acc[5][8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (long long pix = p0; pix < p1; ++pix) {
-    const int q = (int)(pix % g.Q);
-    const long long bp = pix / g.Q;
-    const int p = (int)(bp % g.P), b = (int)(bp / g.P);
-    const int h = p * g.sh - g.ph + r, ww = q * g.sw - g.pw + s;
-    if (h < 0 || h >= g.H || ww < 0 || ww >= g.W) continue;
-    float a[8], d[8];
-    unpack8(x[((size_t)(b * g.H + h) * g.W + ww) * G + cg], a);
-    unpack8(dy[(size_t)pix * G + cg], d);
+  for (int s = 0; s < 5; ++s)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = fmaf(a[e], d[e], acc[e]);
+    for (int e = 0; e < 8; ++e) acc[s][e] = 0.f;
+  if (cg < G) {
+    for (long long pix = p0 + rl; pix < p1; pix += nl) {
+      const int q = (int)(pix % g.Q);
+      const long long bp = pix / g.Q;
+      const int p = (int)(bp % g.P), b = (int)(bp / g.P);
+      const int h = p * g.sh - g.ph + r;
+      if (h < 0 || h >= g.H) continue;
+      float d[8];
+      unpack8(dy[(size_t)pix * G + cg], d);
+      const size_t rowbase = (size_t)(b * g.H + h) * g.W;
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const int ww = q * g.sw - g.pw + s;
+        if (s < g.S && ww >= 0 && ww < g.W) {
+          float a[8];
+          unpack8(x[(rowbase + ww) * G + cg], a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[s][e] = fmaf(a[e], d[e], acc[s][e]);
+        }
+      }
+    }
   }
-  float* out = part + ((size_t)blockIdx.y * RS + tap) * g.C + cg * 8;
-  *reinterpret_cast<float4*>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  *reinterpret_cast<float4*>(out + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][s * 8 + e] = acc[s][e];
+  __syncthreads();
+  if (rl == 0 && cg < G) {
+    for (int s = 0; s < g.S; ++s) {
+      float out[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = 0.f;
+        for (int l = 0; l < nl; ++l) a += red[l * Gp + cl][s * 8 + e];
+        out[e] = a;
+      }
+      float* dst = part + ((size_t)blockIdx.y * RS + r * g.S + s) * g.C + cg * 8;
+      *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(out[4], out[5], out[6], out[7]);
+    }
+  }
 }
 
 // dw[c][r][s] += sum_slab part[slab][tap][c]   (slabs split over gridDim.y, a few-way atomic per element)
@@ -194,6 +223,12 @@ __global__ __launch_bounds__(256) void se_sum_kernel(const uint4* __restrict__ x
   }
 }
 
+static inline int se_gp(int C) {
+  int gp = 1;
+  while (gp < C / 8 && gp < 256) gp <<= 1;
+  return gp;
+}
+
 static inline unsigned dw_grid(long long n) {
   long long g = (n + 255) / 256;
   return (unsigned)(g < 16384 ? (g < 1 ? 1 : g) : 16384);
@@ -206,8 +241,8 @@ static inline bool dw_geom(DwGeom* g, int B, int H, int W, int C, int R, int S, 
   return B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && g->P > 0 && g->Q > 0;
 }
 
-static inline int dw_pix_per_slab(long long npix) {      // at most 512 slabs of at least 256 pixels
-  long long p = (npix + 511) / 512;
+static inline int dw_pix_per_slab(long long npix) {      // at most 1024 slabs of at least 256 pixels
+  long long p = (npix + 1023) / 1024;
   return (int)(p < 256 ? 256 : p);
 }
 
@@ -247,7 +282,9 @@ int mpr_dwconv_wgrad(const void* x, const void* dy, float* dw, float* workspace,
   const int pps = dw_pix_per_slab(npix);
   const int slabs = (int)((npix + pps - 1) / pps);
   hipStream_t st = (hipStream_t)stream;
-  dw_wgrad_kernel<<<dim3(ceil_div(R * S * (C / 8), 256), slabs), 256, 0, st>>>((const uint4*)x, (const uint4*)dy, workspace, g, pps);
+  MPR_REQUIRE(S <= 5 && R <= 65535, "mpr_dwconv_wgrad: filter rows of at most 5 taps (S=%d)", S);
+  const int gp = se_gp(C);
+  dw_wgrad_kernel<<<dim3(ceil_div(C / 8, gp), slabs, R), 256, 0, st>>>((const uint4*)x, (const uint4*)dy, workspace, g, pps, gp);
   MPR_LAUNCH_CHECK("dw_wgrad_kernel");
   if (!accumulate) MPR_HIP(hipMemsetAsync(dw, 0, sizeof(float) * R * S * C, st));
   dw_wgrad_reduce_kernel<<<dim3(ceil_div(R * S * C, 256), slabs >= 32 ? 16 : 1), 256, 0, st>>>(workspace, dw, slabs, R * S, C);
@@ -260,12 +297,6 @@ int mpr_se_scale(const void* x, const float* gate, void* y, int B, int L, int C,
   se_scale_kernel<<<dw_grid((long long)B * L * (C / 8)), 256, 0, (hipStream_t)stream>>>((const uint4*)x, gate, (uint4*)y, B, L, C);
   MPR_LAUNCH_CHECK("se_scale_kernel");
   return MPR_OK;
-}
-
-static inline int se_gp(int C) {
-  int gp = 1;
-  while (gp < C / 8 && gp < 256) gp <<= 1;
-  return gp;
 }
 
 int mpr_se_dgate(const void* x, const void* dy, float* dgate, int B, int L, int C, void* stream) {
