@@ -269,6 +269,14 @@ int mpr_clip_block_fwd(const float* S, const float* logit_scale, float* row_lse,
 int mpr_clip_block_bwd(float* S, const float* logit_scale, const float* lse_own, const float* lse_other,
                        const float* gout /* [1] or NULL */, float coef, float* d_logit_scale_part, float* workspace,
                        int rows, int ncols, int diag_off, void* stream);
+/* data-parallel row block of the SigLIP loss: unnormalised sum of -logsigmoid over the block; gradient scaled by coef */
+int mpr_siglip_block_fwd(const float* S, const float* logit_scale, const float* bias, float* sum_out, float* workspace,
+                         int rows, int ncols, int diag_off, void* stream);
+int mpr_siglip_block_bwd(float* S, const float* logit_scale, const float* bias, float coef,
+                         float* d_logit_scale_part /* may be NULL */, float* d_bias_part /* may be NULL */,
+                         float* workspace, int rows, int ncols, int diag_off, void* stream);
+int mpr_sqdiff_sum(const float* a, const float* b, float* out /* [1] = sum (a-b)^2 */, float* workspace, long long total,
+                   void* stream);
 int mpr_siglip_fwd(const float* S, const float* logit_scale, const float* bias, float* loss, float* workspace,
                    int buckets, int n, void* stream);
 int mpr_siglip_bwd(float* S, const float* logit_scale, const float* bias, const float* gout, float* d_logit_scale,

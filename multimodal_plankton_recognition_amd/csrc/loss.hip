@@ -477,3 +477,93 @@ int mpr_rank_bwd(float* G, const float* row_sum, const float* col_sum, float mar
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- SigLIP, row block
+// Data-parallel SigLIP (extension of src/coordination.py:76-95 to a batch sharded over ranks): S_blk [rows][ncols] holds the
+// raw cosines of this rank's rows against ALL columns, the positive of row i sits at column diag_off + i.  Every (i, j)
+// pair belongs to exactly one rank's row block, so loss and parameter gradients are plain sums over ranks.
+__global__ __launch_bounds__(256) void siglip_block_fwd_kernel(const float* __restrict__ S, const float* __restrict__ ls,
+                                                               const float* __restrict__ bias, float* __restrict__ part,
+                                                               int ncols, int diag_off, long long total) {
+  __shared__ float red[4];
+  const float scale = expf(ls[0]), b = bias[0];
+  float a = 0.f;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int i = (int)(idx / ncols), j = (int)(idx - (long long)i * ncols);
+    const float z = fmaf(S[idx], scale, b);
+    a -= log_sigmoid(j == diag_off + i ? z : -z);
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// S <- coef * dLoss/dS_raw in place; part[0][grid] / part[1][grid]: d(logit_scale) / d(bias) partials of this block
+__global__ __launch_bounds__(256) void siglip_block_grad_kernel(float* __restrict__ S, const float* __restrict__ ls,
+                                                                const float* __restrict__ bias, float* __restrict__ part,
+                                                                int ncols, int diag_off, long long total, float coef) {
+  __shared__ float red[2][4];
+  const float scale = expf(ls[0]), b = bias[0];
+  float dls = 0.f, db = 0.f;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int i = (int)(idx / ncols), j = (int)(idx - (long long)i * ncols);
+    const float l = S[idx] * scale, z = l + b;
+    const float sg = j == diag_off + i ? 1.f : -1.f;
+    const float g = -sg * coef / (1.f + expf(sg * z));
+    dls = fmaf(g, l, dls);
+    db += g;
+    S[idx] = g * scale;
+  }
+  dls = wave_sum(dls);
+  db = wave_sum(db);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dls; red[1][threadIdx.x >> 6] = db; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    part[gridDim.x + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+extern "C" {
+
+int mpr_siglip_block_fwd(const float* S, const float* logit_scale, const float* bias, float* sum_out, float* workspace,
+                         int rows, int ncols, int diag_off, void* stream) {
+  MPR_REQUIRE(S && logit_scale && bias && sum_out && workspace && rows > 0 && ncols > 0, "mpr_siglip_block_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)rows * ncols;
+  const int grid = (int)((total + 255) / 256 < LOSS_GRID ? (total + 255) / 256 : LOSS_GRID);
+  siglip_block_fwd_kernel<<<grid, 256, 0, st>>>(S, logit_scale, bias, workspace, ncols, diag_off, total);
+  MPR_LAUNCH_CHECK("siglip_block_fwd_kernel");
+  finish_sum_kernel<<<1, 256, 0, st>>>(workspace, grid, 1.f, nullptr, sum_out, 0);
+  MPR_LAUNCH_CHECK("finish_sum_kernel");
+  return MPR_OK;
+}
+
+int mpr_siglip_block_bwd(float* S, const float* logit_scale, const float* bias, float coef, float* d_logit_scale_part,
+                         float* d_bias_part, float* workspace, int rows, int ncols, int diag_off, void* stream) {
+  MPR_REQUIRE(S && logit_scale && bias && workspace && rows > 0 && ncols > 0, "mpr_siglip_block_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)rows * ncols;
+  const int grid = (int)((total + 255) / 256 < LOSS_GRID ? (total + 255) / 256 : LOSS_GRID);
+  siglip_block_grad_kernel<<<grid, 256, 0, st>>>(S, logit_scale, bias, workspace, ncols, diag_off, total, coef);
+  MPR_LAUNCH_CHECK("siglip_block_grad_kernel");
+  if (d_logit_scale_part) finish_sum_kernel<<<1, 256, 0, st>>>(workspace, grid, 1.f, nullptr, d_logit_scale_part, 0);
+  if (d_bias_part) finish_sum_kernel<<<1, 256, 0, st>>>(workspace + grid, grid, 1.f, nullptr, d_bias_part, 0);
+  MPR_LAUNCH_CHECK("finish_sum_kernel");
+  return MPR_OK;
+}
+
+// out[0] = sum (a - b)^2   (the local share of the MSE term of CLIPPlus / SigLIPPlus, src/coordination.py:60-64,108-112)
+int mpr_sqdiff_sum(const float* a, const float* b, float* out, float* workspace, long long total, void* stream) {
+  MPR_REQUIRE(a && b && out && workspace && total > 0, "mpr_sqdiff_sum: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (int)((total + 255) / 256 < LOSS_GRID ? (total + 255) / 256 : LOSS_GRID);
+  sqdiff_partial_kernel<<<grid, 256, 0, st>>>(a, b, workspace, total);
+  MPR_LAUNCH_CHECK("sqdiff_partial_kernel");
+  finish_sum_kernel<<<1, 256, 0, st>>>(workspace, grid, 1.f, nullptr, out, 0);
+  MPR_LAUNCH_CHECK("finish_sum_kernel");
+  return MPR_OK;
+}
+
+}  // extern "C"

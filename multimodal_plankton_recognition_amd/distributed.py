@@ -129,14 +129,78 @@ class HipClipMath:
     def matmul(self, g, y_all):
         return ops.gemm(g, y_all)
 
-    def normalize_bwd(self, du, u, inv):
+    def normalize_bwd(self, du, u, inv, x=None, other=None, mse_coef=0.0):
+        """+ mse_coef * (x - other): the local gradient of the MSE term of the *Plus losses."""
         dx = torch.empty_like(u)
-        N.call('mpr_l2norm_bwd', du, u, inv, None, None, 0.0, None, dx, u.shape[0], u.shape[1])
+        N.call('mpr_l2norm_bwd', du, u, inv, x, other, float(mse_coef), None, dx, u.shape[0], u.shape[1])
         return dx
 
+    # ---- SigLIP row block
+    def siglip_block_fwd(self, S, logit_scale, bias, off):
+        rows, ncols = S.shape
+        total = torch.empty((), dtype=F32, device=S.device)
+        N.call('mpr_siglip_block_fwd', S, logit_scale.detach(), bias.detach(), total, self._ws(S.device), rows, ncols, off)
+        return total
 
-def dp_clip(image_emb, profile_emb, logit_scale, comm, math):
-    """Sharded CLIP loss (src/coordination.py:26-47 over the GLOBAL batch, buckets = 1).
+    def siglip_block_bwd(self, S, logit_scale, bias, off, coef, want_param_grads):
+        rows, ncols = S.shape
+        dls = torch.empty((), dtype=F32, device=S.device) if want_param_grads else None
+        db = torch.empty((), dtype=F32, device=S.device) if want_param_grads else None
+        N.call('mpr_siglip_block_bwd', S, logit_scale.detach(), bias.detach(), float(coef), dls, db, self._ws(S.device),
+               rows, ncols, off)
+        return dls, db
+
+    def sqdiff_sum(self, a, b):
+        out = torch.empty((), dtype=F32, device=a.device)
+        N.call('mpr_sqdiff_sum', a.contiguous(), b.contiguous(), out, self._ws(a.device), a.numel())
+        return out
+
+
+def _mse_term(image_emb, profile_emb, beta, n, comm, math):
+    """beta * MSELoss(image_emb, profile_emb) over the GLOBAL batch (src/coordination.py:60-64,108-112):
+    -> (loss share summed over ranks, coefficient of (x - other) in the local embedding gradients)."""
+    if not beta:
+        return None, 0.0
+    D = image_emb.shape[1]
+    local = math.sqdiff_sum(image_emb.detach().float(), profile_emb.detach().float())
+    total = comm.all_reduce_sum(local.reshape(1).clone()).reshape(())
+    return total * (float(beta) / (n * D)), 2.0 * float(beta) / (n * D)
+
+
+def dp_siglip(image_emb, profile_emb, logit_scale, bias, comm, math, beta=0.0):
+    """Sharded SigLIP loss (src/coordination.py:76-95 over the GLOBAL batch, buckets = 1; + beta * MSE for SigLIPPlus).
+
+    Every (image i, profile j) pair is owned by the rank that owns row i: the loss and the parameter gradients are sums of
+    the row-block shares.  The profile gradients need column j against ALL images, so each rank also forms its column block
+    V_loc U_all^T (the pair function is symmetric in its two roles) -- twice the tiny GEMM instead of a reduce-scatter of
+    [n, D] gradients.  Returns (loss, dL/d image_emb, dL/d profile_emb, d logit_scale share, d bias share)."""
+    b = image_emb.shape[0]
+    n = b * comm.world
+    off = comm.rank * b
+    u, iu = math.normalize(image_emb)
+    v, iv = math.normalize(profile_emb)
+    both = comm.all_gather(torch.stack((u, v)))                      # [world, 2, b, D]
+    D = u.shape[1]
+    u_all = both[:, 0].reshape(n, D).contiguous()
+    v_all = both[:, 1].reshape(n, D).contiguous()
+    s_img = math.logits(u, v_all)
+    s_prof = math.logits(v, u_all)
+    share = math.siglip_block_fwd(s_img, logit_scale, bias, off)
+    loss = comm.all_reduce_sum((share / n).reshape(1).clone()).reshape(())
+    mse, mse_coef = _mse_term(image_emb, profile_emb, beta, n, comm, math)
+    if mse is not None:
+        loss = loss + mse
+    coef = 1.0 / n
+    dls, db = math.siglip_block_bwd(s_img, logit_scale, bias, off, coef, True)       # s_img  <- G
+    math.siglip_block_bwd(s_prof, logit_scale, bias, off, coef, False)               # s_prof <- G^T (my columns)
+    a32, p32 = image_emb.detach().float().contiguous(), profile_emb.detach().float().contiguous()
+    d_img = math.normalize_bwd(math.matmul(s_img, v_all), u, iu, a32 if beta else None, p32 if beta else None, mse_coef)
+    d_prof = math.normalize_bwd(math.matmul(s_prof, u_all), v, iv, p32 if beta else None, a32 if beta else None, mse_coef)
+    return loss, d_img, d_prof, dls, db
+
+
+def dp_clip(image_emb, profile_emb, logit_scale, comm, math, beta=0.0):
+    """Sharded CLIP loss (src/coordination.py:26-47 over the GLOBAL batch, buckets = 1; + beta * MSE for CLIPPlus).
 
     Returns (loss [global value, identical on every rank], dL/d image_emb, dL/d profile_emb,
     d logit_scale [this rank's partial: the total is the SUM over ranks])."""
@@ -160,19 +224,33 @@ def dp_clip(image_emb, profile_emb, logit_scale, comm, math):
     coef = 1.0 / (2.0 * n)
     dls = math.block_bwd(s_img, logit_scale, lse_r, lse_c_all, off, coef)      # s_img  <- G  * scale
     math.block_bwd(s_prof, logit_scale, lse_c, lse_r_all, off, coef)           # s_prof <- G^T * scale (my columns)
-    d_img = math.normalize_bwd(math.matmul(s_img, v_all), u, iu)
-    d_prof = math.normalize_bwd(math.matmul(s_prof, u_all), v, iv)
+    if beta:
+        mse, mse_coef = _mse_term(image_emb, profile_emb, beta, n, comm, math)
+        loss = loss + mse
+        a32, p32 = image_emb.detach().float().contiguous(), profile_emb.detach().float().contiguous()
+        d_img = math.normalize_bwd(math.matmul(s_img, v_all), u, iu, a32, p32, mse_coef)
+        d_prof = math.normalize_bwd(math.matmul(s_prof, u_all), v, iv, p32, a32, mse_coef)
+    else:
+        d_img = math.normalize_bwd(math.matmul(s_img, v_all), u, iu)
+        d_prof = math.normalize_bwd(math.matmul(s_prof, u_all), v, iv)
     return loss, d_img, d_prof, dls
 
 
 # ------------------------------------------------------------------------------------------------ DP step
 class DataParallelStep:
-    """zero_grad -> encode (local) -> sharded CLIP -> backward -> flat SUM all-reduce -> fused SGD."""
+    """zero_grad -> encode (local) -> sharded CLIP / SigLIP (+ MSE) -> backward -> flat SUM all-reduce -> fused SGD."""
 
     def __init__(self, model, optimizer, world, comm=None, math=None):
-        from .coordination import CLIPLoss
-        if not isinstance(model.loss, CLIPLoss):
-            raise NotImplementedError('data-parallel step: only method "clip" has a sharded loss so far')
+        from .coordination import CLIPLoss, CLIPPlus, SigLIPLoss, SigLIPPlus
+        loss = model.loss
+        if isinstance(loss, (CLIPLoss, CLIPPlus)):
+            self.kind, self.core = 'clip', (loss if isinstance(loss, CLIPLoss) else loss.clip)
+        elif isinstance(loss, (SigLIPLoss, SigLIPPlus)):
+            self.kind, self.core = 'siglip', (loss if isinstance(loss, SigLIPLoss) else loss.siglip)
+        else:
+            raise NotImplementedError('data-parallel step: clip / siglip (+ Plus) have sharded losses; "rank" cannot train '
+                                      'in the reference either')
+        self.beta = float(getattr(loss, 'beta', 0.0)) if isinstance(loss, (CLIPPlus, SigLIPPlus)) else 0.0
         self.model, self.opt = model, optimizer
         self.comm = comm or Comm()
         self.math = math or HipClipMath()
@@ -197,19 +275,27 @@ class DataParallelStep:
         if batch.get('buckets', 1) != 1:
             raise NotImplementedError('data-parallel step: buckets must be 1 (the global batch is one bucket)')
         emb = model.encode(**batch)
-        loss, d_img, d_prof, dls = dp_clip(emb['image_emb'], emb['profile_emb'], model.loss.logit_scale,
-                                           self.comm, self.math)
+        core = self.core
+        if self.kind == 'clip':
+            loss, d_img, d_prof, dls = dp_clip(emb['image_emb'], emb['profile_emb'], core.logit_scale, self.comm,
+                                               self.math, self.beta)
+            pgrads = [(core.logit_scale, dls)]
+        else:
+            loss, d_img, d_prof, dls, db = dp_siglip(emb['image_emb'], emb['profile_emb'], core.logit_scale, core.bias,
+                                                     self.comm, self.math, self.beta)
+            pgrads = [(core.logit_scale, dls), (core.bias, db)]
         torch.autograd.backward([emb['image_emb'], emb['profile_emb']], [d_img, d_prof])
-        ls = model.loss.logit_scale
         arena = getattr(self.opt, 'flat_grad', None)
-        if arena is not None and getattr(ls, '_mpr_grad', None) is ls.grad:
+        if arena is not None and all(getattr(p, '_mpr_grad', None) is p.grad for p, _ in pgrads):
             # FusedSGD: every gradient already sits in the optimizer's flat buffer (the fused backward Functions
             # accumulate into it) -- ONE all-reduce of that buffer, no gather copies
-            ls.grad.add_(dls.reshape(ls.shape))
-            ls._mpr_touched = True
+            for p, g in pgrads:
+                p.grad.add_(g.reshape(p.shape))
+                p._mpr_touched = True
             self.comm.all_reduce_sum(arena)
         else:
-            ls.grad = dls
+            for p, g in pgrads:
+                p.grad = g.reshape(p.shape)
             flat, views = self._flat_views()
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
             torch._foreach_copy_(views, grads)

@@ -43,8 +43,30 @@ class TorchMath:
     def matmul(self, g, y_all):
         return g @ y_all
 
-    def normalize_bwd(self, du, u, inv):
-        return inv[:, None] * (du - u * (u * du).sum(1, keepdim=True))
+    def normalize_bwd(self, du, u, inv, x=None, other=None, mse_coef=0.0):
+        dx = inv[:, None] * (du - u * (u * du).sum(1, keepdim=True))
+        return dx + mse_coef * (x - other) if mse_coef else dx
+
+    def siglip_block_fwd(self, S, logit_scale, bias, off):
+        z = S * logit_scale.detach().exp() + bias.detach()
+        sg = -torch.ones_like(z)
+        idx = torch.arange(S.shape[0])
+        sg[idx, off + idx] = 1
+        return -torch.nn.functional.logsigmoid(sg * z).sum()
+
+    def siglip_block_bwd(self, S, logit_scale, bias, off, coef, want_param_grads):
+        scale = logit_scale.detach().exp()
+        l = S * scale
+        z = l + bias.detach()
+        sg = -torch.ones_like(z)
+        idx = torch.arange(S.shape[0])
+        sg[idx, off + idx] = 1
+        g = -sg * coef * torch.sigmoid(-sg * z)
+        S.copy_(g * scale)
+        return ((g * l).sum(), g.sum()) if want_param_grads else (None, None)
+
+    def sqdiff_sum(self, a, b):
+        return ((a - b) ** 2).sum()
 
 
 def _free_port():
@@ -91,3 +113,56 @@ def test_sharded_clip_equals_global_oracle(world, b, d):
         np.testing.assert_allclose(d_img, a.grad[sl].numpy(), rtol=1e-4, atol=1e-7)
         np.testing.assert_allclose(d_prof, p.grad[sl].numpy(), rtol=1e-4, atol=1e-7)
         assert abs(dls_total - ls.grad.item()) < 1e-5
+
+
+def _worker_general(rank, world, port, b, d, method, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from multimodal_plankton_recognition_amd import distributed as D
+    torch.set_num_threads(1)
+    D.init(backend='gloo')
+    rs = np.random.RandomState(11)
+    a_all = torch.from_numpy(rs.standard_normal((world * b, d)).astype(np.float32))
+    p_all = torch.from_numpy((rs.standard_normal((world * b, d)) * 1.5 + 0.1).astype(np.float32))
+    ls, bias = torch.tensor(1.3), torch.tensor(-4.0)
+    sl = slice(rank * b, (rank + 1) * b)
+    beta = .25 if method.endswith('plus') else 0.0
+    comm = D.Comm()
+    if method.startswith('siglip'):
+        loss, d_img, d_prof, dls, db = D.dp_siglip(a_all[sl], p_all[sl], ls, bias, comm, TorchMath(), beta)
+        db_total = comm.all_reduce_sum(db.reshape(1).clone()).item()
+    else:
+        loss, d_img, d_prof, dls = D.dp_clip(a_all[sl], p_all[sl], ls, comm, TorchMath(), beta)
+        db_total = 0.0
+    dls_total = comm.all_reduce_sum(dls.reshape(1).clone()).item()
+    out[rank] = (loss.item(), d_img.numpy(), d_prof.numpy(), dls_total, db_total)
+    D.barrier()
+    D.shutdown()
+
+
+@pytest.mark.parametrize('method', ['siglip', 'siglipplus', 'clipplus'])
+@pytest.mark.parametrize('world,b,d', [(2, 6, 16), (4, 3, 8)])
+def test_sharded_siglip_and_plus_losses_equal_global_oracle(world, b, d, method):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_general, args=(world, _free_port(), b, d, method, out), nprocs=world, join=True)
+    rs = np.random.RandomState(11)
+    a = torch.from_numpy(rs.standard_normal((world * b, d)).astype(np.float32)).requires_grad_(True)
+    p = torch.from_numpy((rs.standard_normal((world * b, d)) * 1.5 + 0.1).astype(np.float32)).requires_grad_(True)
+    ls = torch.tensor(1.3, requires_grad=True)
+    bias = torch.tensor(-4.0, requires_grad=True)
+    if method == 'siglip':
+        ref = OC.siglip_loss(a, p, ls, bias, 1)
+    elif method == 'siglipplus':
+        ref = OC.siglip_plus(a, p, ls, bias, 1, .25)
+    else:
+        ref = OC.clip_plus(a, p, ls, 1, .25)
+    ref.backward()
+    for rank in range(world):
+        loss, d_img, d_prof, dls_total, db_total = out[rank]
+        sl = slice(rank * b, (rank + 1) * b)
+        assert abs(loss - ref.item()) < 1e-4 * max(1.0, abs(ref.item()))
+        np.testing.assert_allclose(d_img, a.grad[sl].numpy(), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(d_prof, p.grad[sl].numpy(), rtol=2e-4, atol=1e-6)
+        assert abs(dls_total - ls.grad.item()) < 1e-4 * max(1.0, abs(ls.grad.item()))
+        if method.startswith('siglip'):
+            assert abs(db_total - bias.grad.item()) < 1e-4 * max(1.0, abs(bias.grad.item()))
