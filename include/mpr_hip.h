@@ -314,6 +314,15 @@ int mpr_se_scale(const void* x /* [B][L][C] bf16 */, const float* gate /* [B][C]
 int mpr_se_dgate(const void* x, const void* dy, float* dgate /* [B][C] = sum_l dy * x */, int B, int L, int C, void* stream);
 int mpr_se_pool(const void* x, float* pooled /* [B][C] = mean_l x */, int B, int L, int C, void* stream);
 
+/* ---- input pipeline, the per-step random part on pre-decoded batches (src/data.py:73-91,124-141,198-204): the random
+ *      decisions (crop offsets, flips) are INPUTS (int32 / byte vectors of length B) */
+int mpr_aug_image(const void* src_u8 /* [B][S][S] gray bytes, S = ceil(1.05 T) */, const int* top, const int* left,
+                  const void* vflip, const void* hflip, float* dst /* [B][1][T][T] in [-1, 1] */, int B, int S, int T,
+                  void* stream);
+int mpr_aug_profile(const float* raw /* [B][Lmax][C] raw counts, zero-padded */, const int* length, const int* left,
+                    const void* reverse, const float* ceiling /* [C] log-scale ceilings */, float* dst /* [B][T][C] */,
+                    int B, int Lmax, int C, int S, int T, float sigma, unsigned seed, void* stream);
+
 /* ---- few-shot evaluation: exact k-nearest neighbours + weighted vote (src/ann.py:6-34 as driven by
  *      scripts/benchmark_cross.py:24-96; the reference's approximate NN-descent index is replaced by exact search) */
 int mpr_knn_sqnorm(const float* X, float* out /* [rows] */, int rows, int D, void* stream);
