@@ -437,24 +437,38 @@ __device__ __forceinline__ uint4 add_bias8(const uint4& v, const float* bias) {
 
 // Stage rows [0, Tp) x HD of one (token-major, row stride `ld` elements) operand into LDS: row image (row stride RS bytes)
 // and / or transposed image (row stride TS bytes, [HD][Tp]); rows >= T are zero.
+// Staging of one (token-major, row stride `ld` elements) operand of a (batch, head) into LDS, in two phases so that the
+// loads of SEVERAL operands are in flight together before the first LDS write (one memory latency per kernel, not one per
+// operand): stage_load issues the 16-byte loads of rows [0, Tp) (rows >= T: zeros), stage_store adds the bias and writes the
+// row image (row stride RS bytes) and / or the transposed image ([HD][Tp], row stride TS bytes).
 template <int HD>
-__device__ __forceinline__ void stage_operand(const uint16_t* __restrict__ src, size_t ld, const float* __restrict__ bias,
-                                              int T, int Tp, unsigned char* rows, int RS, unsigned char* trans, int TS) {
-  constexpr int G = HD / 8, IT = 256 * G / 512;      // Tp <= 256: at most IT rounds of 512 threads
+struct StageRegs {
+  static constexpr int G = HD / 8, IT = 256 * G / 512;      // Tp <= 256: at most IT rounds of 512 threads
   uint4 v[IT];
+};
+
+template <int HD>
+__device__ __forceinline__ void stage_load(StageRegs<HD>& r, const uint16_t* __restrict__ src, size_t ld, int T) {
+  constexpr int G = HD / 8;
 #pragma unroll
-  for (int it = 0; it < IT; ++it) {                  // every load in flight before the first LDS write
+  for (int it = 0; it < StageRegs<HD>::IT; ++it) {
     const int idx = threadIdx.x + 512 * it;
     const int t = idx / G, g = idx - t * G;
-    v[it] = make_uint4(0, 0, 0, 0);
-    if (t < T) v[it] = *reinterpret_cast<const uint4*>(src + (size_t)t * ld + 8 * g);
+    r.v[it] = make_uint4(0, 0, 0, 0);
+    if (t < T) r.v[it] = *reinterpret_cast<const uint4*>(src + (size_t)t * ld + 8 * g);
   }
+}
+
+template <int HD>
+__device__ __forceinline__ void stage_store(const StageRegs<HD>& r, const float* __restrict__ bias, int T, int Tp,
+                                            unsigned char* rows, int RS, unsigned char* trans, int TS) {
+  constexpr int G = HD / 8;
 #pragma unroll
-  for (int it = 0; it < IT; ++it) {
+  for (int it = 0; it < StageRegs<HD>::IT; ++it) {
     const int idx = threadIdx.x + 512 * it;
     const int t = idx / G, g = idx - t * G;
     if (t >= Tp) continue;
-    const uint4 w = t < T ? add_bias8(v[it], bias ? bias + 8 * g : nullptr) : v[it];
+    const uint4 w = t < T ? add_bias8(r.v[it], bias ? bias + 8 * g : nullptr) : r.v[it];
     if (rows) *reinterpret_cast<uint4*>(rows + t * RS + g * 16) = w;
     if (trans) {
       const uint32_t wds[4] = {w.x, w.y, w.z, w.w};
@@ -490,17 +504,21 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
   const int dm = p.heads * HD;
   const size_t d3 = 3 * (size_t)dm;
   const uint16_t* const base = p.qkv + (size_t)b * p.T * d3 + h * HD;
-  stage_operand<HD>(base + dm, d3, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, nullptr, 0);
-  stage_operand<HD>(base + 2 * dm, d3, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, nullptr, 0, Vt, TS);
-  __syncthreads();
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-  if (w >= nblk) return;
   const int q = 32 * w + r, qc = q < p.T ? q : p.T - 1;
+  StageRegs<HD> rk, rv;
+  stage_load<HD>(rk, base + dm, d3, p.T);
+  stage_load<HD>(rv, base + 2 * dm, d3, p.T);
+  uint4 qraw[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) qraw[c] = *reinterpret_cast<const uint4*>(base + (size_t)qc * d3 + 16 * c + 8 * hh);
+  stage_store<HD>(rk, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, nullptr, 0);
+  stage_store<HD>(rv, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, nullptr, 0, Vt, TS);
+  __syncthreads();
+  if (w >= nblk) return;
   bf16x8 qf[NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
-    qf[c] = as_frag(add_bias8(*reinterpret_cast<const uint4*>(base + (size_t)qc * d3 + 16 * c + 8 * hh),
-                              p.bias ? p.bias + h * HD + 16 * c + 8 * hh : nullptr));
+  for (int c = 0; c < NC; ++c) qf[c] = as_frag(add_bias8(qraw[c], p.bias ? p.bias + h * HD + 16 * c + 8 * hh : nullptr));
   f32x16 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -514,29 +532,43 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
       }
     }
   }
+  // softmax over the keys of this lane's query, in as few VALU instructions per score as possible (they, not the 56
+  // MFMAs, are this kernel's arithmetic): invalid keys (tail of the last block / padding mask) are set to -inf in a
+  // pass that only runs where it can matter; max over the RAW scores (scale > 0), p = exp2(s * c - m * c) with
+  // c = scale * log2(e) as one FMA + v_exp_f32; the 1 / sum normalisation moves behind the P V product.
   const unsigned char* const mrow = p.mask ? p.mask + (size_t)b * p.T : nullptr;
+  // per key block, bit e of bad[j] = accumulator register e holds an invalid key (tail of the last block / padding mask)
+  uint32_t bad[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bad[j] = 0;
+    if (j < nblk && (mrow || j == nblk - 1)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (!(key < p.T && !(mrow && mrow[key]))) bad[j] |= 1u << e;
+      }
+    }
+  }
   float m = -INFINITY;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     if (j < nblk) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        const bool valid = key < p.T && !(mrow && mrow[key]);
-        const float s = valid ? acc[j][e] * p.scale : -INFINITY;
-        acc[j][e] = s;
-        m = fmaxf(m, s);
-      }
+      for (int e = 0; e < 16; ++e)
+        if (!((bad[j] >> e) & 1u)) m = fmaxf(m, acc[j][e]);
     }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   if (m == -INFINITY) m = 0.f;
+  const float c2 = p.scale * 1.4426950408889634f, mc = -m * c2;
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     if (j < nblk) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = __expf(acc[j][e] - m);
+        float pv = __builtin_amdgcn_exp2f(fmaf(acc[j][e], c2, mc));
+        if ((bad[j] >> e) & 1u) pv = 0.f;
         acc[j][e] = pv;
         sum += pv;
       }
@@ -555,23 +587,27 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
     if (j < nblk) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        if (p.p_drop > 0.f) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int e = 8 * s + i;
+            const int key = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (!tb_keep(p.seed, rowi + key, p.p_drop)) acc[j][e] = 0.f;
+          }
+        }
         float pv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int e = 8 * s + i;
-          float v = acc[j][e] * keep_scale;
-          if (p.p_drop > 0.f) {
-            const int key = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            if (!tb_keep(p.seed, rowi + key, p.p_drop)) v = 0.f;
-          }
-          pv[i] = v;
-        }
+        for (int i = 0; i < 8; ++i) pv[i] = acc[j][8 * s + i];
         const bf16x8 pf = acc_frag(pv);
 #pragma unroll
         for (int d = 0; d < ND; ++d)
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(Vt, TS, 32 * d + r, j, s, hh), pf, o[d], 0, 0, 0);
       }
     }
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] *= keep_scale;
   if (q < p.T) {
     uint16_t* const orow = p.out + ((size_t)b * p.T + q) * dm + h * HD;
 #pragma unroll
@@ -581,7 +617,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
         const float f[4] = {o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]};
         *reinterpret_cast<uint2*>(orow + 32 * d + 8 * g + 4 * hh) = pack4(f);
       }
-    if (hh == 0) p.lse[(size_t)blockIdx.x * p.T + q] = m + __logf(sum);
+    if (hh == 0) p.lse[(size_t)blockIdx.x * p.T + q] = m * p.scale + __logf(sum);
   }
 #endif
 }
@@ -600,22 +636,32 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnParams p) {
   const int dm = p.heads * HD;
   const size_t d3 = 3 * (size_t)dm;
   const uint16_t* const base = p.qkv + (size_t)b * p.T * d3 + h * HD;
-  stage_operand<HD>(base + dm, d3, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, Kt, TS);
-  stage_operand<HD>(base + 2 * dm, d3, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, Vs, RS, nullptr, 0);
-  __syncthreads();
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-  if (w >= nblk) return;
   const int q = 32 * w + r, qc = q < p.T ? q : p.T - 1;
-  bf16x8 qf[NC], dof[NC];
-  float delta = 0.f;
   const uint16_t* const dorow = p.dout + ((size_t)b * p.T + qc) * dm + h * HD;
   const uint16_t* const orow = p.out + ((size_t)b * p.T + qc) * dm + h * HD;
+  StageRegs<HD> rk, rv;
+  stage_load<HD>(rk, base + dm, d3, p.T);
+  stage_load<HD>(rv, base + 2 * dm, d3, p.T);
+  uint4 qraw[NC], dvraw[NC], ovraw[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    qf[c] = as_frag(add_bias8(*reinterpret_cast<const uint4*>(base + (size_t)qc * d3 + 16 * c + 8 * hh),
-                              p.bias ? p.bias + h * HD + 16 * c + 8 * hh : nullptr));
-    const uint4 dv = *reinterpret_cast<const uint4*>(dorow + 16 * c + 8 * hh);
-    const uint4 ov = *reinterpret_cast<const uint4*>(orow + 16 * c + 8 * hh);
+    qraw[c] = *reinterpret_cast<const uint4*>(base + (size_t)qc * d3 + 16 * c + 8 * hh);
+    dvraw[c] = *reinterpret_cast<const uint4*>(dorow + 16 * c + 8 * hh);
+    ovraw[c] = *reinterpret_cast<const uint4*>(orow + 16 * c + 8 * hh);
+  }
+  const float lse = p.lse[(size_t)blockIdx.x * p.T + qc];
+  stage_store<HD>(rk, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, Kt, TS);
+  stage_store<HD>(rv, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, Vs, RS, nullptr, 0);
+  __syncthreads();
+  if (w >= nblk) return;
+  bf16x8 qf[NC], dof[NC];
+  float delta = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    qf[c] = as_frag(add_bias8(qraw[c], p.bias ? p.bias + h * HD + 16 * c + 8 * hh : nullptr));
+    const uint4 dv = dvraw[c];
+    const uint4 ov = ovraw[c];
     dof[c] = as_frag(dv);
     float a[8], bq[8];
     unpack8(dv, a);
@@ -624,11 +670,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnParams p) {
     for (int e = 0; e < 8; ++e) delta = fmaf(a[e], bq[e], delta);
   }
   delta += __shfl_xor(delta, 32, 64);
-  const float lse = p.lse[(size_t)blockIdx.x * p.T + qc];
   if (q < p.T && hh == 0) p.delta[(size_t)blockIdx.x * p.T + q] = delta;
   const unsigned char* const mrow = p.mask ? p.mask + (size_t)b * p.T : nullptr;
   const unsigned long long rowi = ((unsigned long long)blockIdx.x * p.T + q) * p.T;
   const float dscale = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+  const float c2 = p.scale * 1.4426950408889634f, nlse2 = -lse * 1.4426950408889634f;
   f32x16 dq[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d)
@@ -646,11 +692,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnParams p) {
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[c], dp, 0, 0, 0);
     }
     float ds[16];
+    const bool check = mrow || j == nblk - 1;        // (wave-uniform) only the last key block has a tail, only masks mask
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hh;
-      const bool valid = key < p.T && !(mrow && mrow[key]);
-      const float pr = valid ? __expf(s[e] * p.scale - lse) : 0.f;
+      float pr = __builtin_amdgcn_exp2f(fmaf(s[e], c2, nlse2));
+      if (check && !(key < p.T && !(mrow && mrow[key]))) pr = 0.f;
       float dpe = dp[e] * dscale;
       if (p.p_drop > 0.f && !tb_keep(p.seed, rowi + key, p.p_drop)) dpe = 0.f;
       ds[e] = pr * (dpe - delta) * p.scale;
@@ -693,26 +740,34 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttnParams p) {
   const int dm = p.heads * HD;
   const size_t d3 = 3 * (size_t)dm;
   const uint16_t* const base = p.qkv + (size_t)b * p.T * d3 + h * HD;
-  stage_operand<HD>(base, d3, p.bias ? p.bias + h * HD : nullptr, p.T, Tp, Qs, RS, Qt, TS);
-  stage_operand<HD>(p.dout + (size_t)b * p.T * dm + h * HD, dm, nullptr, p.T, Tp, Os, RS, Ot, TS);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const int key = 32 * w + r, kc = key < p.T ? key : p.T - 1;
+  StageRegs<HD> rq, ro;
+  stage_load<HD>(rq, base, d3, p.T);
+  stage_load<HD>(ro, p.dout + (size_t)b * p.T * dm + h * HD, dm, p.T);
+  uint4 kraw[NC], vraw[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    kraw[c] = *reinterpret_cast<const uint4*>(base + dm + (size_t)kc * d3 + 16 * c + 8 * hh);
+    vraw[c] = *reinterpret_cast<const uint4*>(base + 2 * dm + (size_t)kc * d3 + 16 * c + 8 * hh);
+  }
   for (int t = threadIdx.x; t < Tp; t += 512) {
-    lse_s[t] = t < p.T ? p.lse[(size_t)blockIdx.x * p.T + t] : 0.f;
+    lse_s[t] = t < p.T ? -1.4426950408889634f * p.lse[(size_t)blockIdx.x * p.T + t] : 0.f;     // (-lse * log2 e)
     del_s[t] = t < p.T ? p.delta[(size_t)blockIdx.x * p.T + t] : 0.f;
   }
+  stage_store<HD>(rq, p.bias ? p.bias + h * HD : nullptr, p.T, Tp, Qs, RS, Qt, TS);
+  stage_store<HD>(ro, nullptr, p.T, Tp, Os, RS, Ot, TS);
   __syncthreads();
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   if (w >= nblk) return;
-  const int key = 32 * w + r, kc = key < p.T ? key : p.T - 1;
   const bool key_valid = key < p.T && !(p.mask && p.mask[(size_t)b * p.T + kc]);
   bf16x8 kf[NC], vf[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    kf[c] = as_frag(add_bias8(*reinterpret_cast<const uint4*>(base + dm + (size_t)kc * d3 + 16 * c + 8 * hh),
-                              p.bias ? p.bias + dm + h * HD + 16 * c + 8 * hh : nullptr));
-    vf[c] = as_frag(add_bias8(*reinterpret_cast<const uint4*>(base + 2 * dm + (size_t)kc * d3 + 16 * c + 8 * hh),
-                              p.bias ? p.bias + 2 * dm + h * HD + 16 * c + 8 * hh : nullptr));
+    kf[c] = as_frag(add_bias8(kraw[c], p.bias ? p.bias + dm + h * HD + 16 * c + 8 * hh : nullptr));
+    vf[c] = as_frag(add_bias8(vraw[c], p.bias ? p.bias + 2 * dm + h * HD + 16 * c + 8 * hh : nullptr));
   }
   const float dscale = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+  const float c2 = p.scale * 1.4426950408889634f;
   f32x16 dk[ND], dv[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d)
@@ -734,7 +789,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttnParams p) {
     for (int e = 0; e < 16; ++e) {
       const int q = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
       const bool valid = key_valid && q < p.T;
-      const float pr = valid ? __expf(s[e] * p.scale - lse_s[q]) : 0.f;
+      const float pr = valid ? __builtin_amdgcn_exp2f(fmaf(s[e], c2, lse_s[q])) : 0.f;
       float keepf = dscale;
       if (p.p_drop > 0.f && !tb_keep(p.seed, ((unsigned long long)blockIdx.x * p.T + q) * p.T + key, p.p_drop)) keepf = 0.f;
       pd[e] = pr * keepf;
