@@ -280,17 +280,22 @@ __global__ __launch_bounds__(256) void tf_colsum_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------ elementwise, bf16
-// y = drop(act(x + bias[col]))   (16-byte groups)
+// y = drop(act(x + bias[col]))   (16-byte groups; 32-bit index arithmetic, the bias as two float4 per group)
 __global__ __launch_bounds__(256) void tf_bias_act_fwd_kernel(const uint4* __restrict__ x, const float* __restrict__ bias,
                                                               int act, float p_drop, uint32_t seed, uint4* __restrict__ y,
                                                               long long ngroups, int D) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ngroups; i += (long long)gridDim.x * 256) {
+  const uint32_t G = (uint32_t)D / 8, n = (uint32_t)ngroups, stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     float f[8];
     unpack8(x[i], f);
-    const int col = (int)((i * 8) % D);
+    if (bias) {
+      const uint32_t col = (i % G) * 8;
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+      f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = act_fwd(f[e] + (bias ? bias[col + e] : 0.f), act);
+      float v = act_fwd(f[e], act);
       if (p_drop > 0.f) v = tb_keep(seed, (unsigned long long)i * 8 + e, p_drop) ? v / (1.f - p_drop) : 0.f;
       f[e] = v;
     }
@@ -339,9 +344,13 @@ __global__ __launch_bounds__(256) void tf_ew_bwd_flat_kernel(const EwBwdParams p
     if (MODE == 1 && p.act != 0) {
       float xv[8];
       unpack8(*reinterpret_cast<const uint4*>(p.x + o), xv);
-      const int col = (int)(o % p.D);
+      if (p.bias) {
+        const int col = (int)(o % p.D);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] *= act_grad(xv[e] + (p.bias ? p.bias[col + e] : 0.f), p.act);
+        for (int e = 0; e < 8; ++e) xv[e] += p.bias[col + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] *= act_grad(xv[e], p.act);
     }
     *reinterpret_cast<uint4*>(p.dx + o) = pack8(g);
   }
@@ -890,6 +899,7 @@ int mpr_tf_bias_act_fwd(const void* x, const float* bias, int act, float p_drop,
                         void* stream) {
   MPR_REQUIRE(x && y && rows > 0 && D > 0 && D % 8 == 0 && act >= 0 && act <= 4, "mpr_tf_bias_act_fwd: bad arguments (D=%d)", D);
   const long long ng = rows * D / 8;
+  MPR_REQUIRE(ng < (1ll << 31), "mpr_tf_bias_act_fwd: tensor too large (%lld groups)", ng);
   tf_bias_act_fwd_kernel<<<tb_grid(ng), 256, 0, (hipStream_t)stream>>>((const uint4*)x, bias, act, p_drop, seed, (uint4*)y, ng, D);
   MPR_LAUNCH_CHECK("tf_bias_act_fwd_kernel");
   return MPR_OK;
@@ -897,7 +907,7 @@ int mpr_tf_bias_act_fwd(const void* x, const float* bias, int act, float p_drop,
 
 static inline void ew_bwd_grid(int rows, int D, int* gx, int* slabs, int* rps) {
   *gx = ceil_div(D, 512);
-  int n = 1024 / *gx;
+  int n = 4096 / *gx;          // ~16 workgroups per CU: enough loads in flight to cover the memory latency
   if (n > ceil_div(rows, 8)) n = ceil_div(rows, 8);
   if (n < 1) n = 1;
   *rps = ceil_div(rows, n);
