@@ -127,7 +127,8 @@ int mpr_bn_eval_coefs(const float* gamma, const float* beta, const float* runnin
                       float eps, float* scale, float* shift, int C, void* stream);
 int mpr_bn_apply(const void* x, const float* scale, const float* shift, const void* residual /* may be NULL */,
                  int relu, void* y, long long rows, int C, void* stream);
-/* mask_mode: 0 = dz = dy; 1 = dz = dy * (y > 0); 2 = dz = dy * (x*scale+shift > 0) */
+/* mask_mode: 0 = dz = dy; 1 = dz = dy * (y > 0); 2 = dz = dy * (x*scale+shift > 0); 3 = dz = dy * silu'(x*scale+shift)
+ * (mpr_bn_apply's `relu` argument: 0 none, 1 ReLU, 2 SiLU) */
 int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                       const float* scale, const float* shift, int mask_mode, float* partials, long long rows, int C,
                       void* stream);

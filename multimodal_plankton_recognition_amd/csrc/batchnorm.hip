@@ -244,7 +244,8 @@ __device__ __forceinline__ void bn_block_finalize(const float* __restrict__ slic
   __syncthreads();
 }
 
-template <bool RELU, bool RES>
+// ACT: 0 none, 1 ReLU, 2 SiLU (EfficientNet's BatchNormAct2d)
+template <int ACT, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const bf16_t* __restrict__ res, bf16_t* __restrict__ y,
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
     for (int e = 0; e < 8; ++e) {
       float t = fmaf(f[e], sc[e], sh[e]);
       if (RES) t += r[e];
-      if (RELU) t = fmaxf(t, 0.f);
+      if (ACT == 1) t = fmaxf(t, 0.f);
+      if (ACT == 2) t = t / (1.f + __expf(-t));
       f[e] = t;
     }
     reinterpret_cast<uint4*>(y)[v] = pack8(f);
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
 }
 
 // mask modes for the backward passes
-enum { MASK_NONE = 0, MASK_Y = 1, MASK_RECOMPUTE = 2 };
+enum { MASK_NONE = 0, MASK_Y = 1, MASK_RECOMPUTE = 2, MASK_SILU = 3 };   // MASK_SILU: dz = dy * silu'(x*scale + shift)
 
 template <int MODE>
 __device__ __forceinline__ void masked_dz(const uint4* dy, const uint4* ymask, const float* xf, const float* sc,
@@ -296,6 +298,12 @@ __device__ __forceinline__ void masked_dz(const uint4* dy, const uint4* ymask, c
   } else if (MODE == MASK_RECOMPUTE) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dz[e] = round_bf16(fmaf(xf[e], sc[e], sh[e])) > 0.f ? dz[e] : 0.f;
+  } else if (MODE == MASK_SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = fmaf(xf[e], sc[e], sh[e]), sg = 1.f / (1.f + __expf(-t));
+      dz[e] *= sg * fmaf(t, 1.f - sg, 1.f);
+    }
   }
 }
 
@@ -314,8 +322,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   for (int e = 0; e < 8; ++e) {
     mu[e] = mean[g * 8 + e];
     is[e] = invstd[g * 8 + e];
-    sc[e] = MODE == MASK_RECOMPUTE ? scale[g * 8 + e] : 0.f;
-    sh[e] = MODE == MASK_RECOMPUTE ? shift[g * 8 + e] : 0.f;
+    sc[e] = MODE >= MASK_RECOMPUTE ? scale[g * 8 + e] : 0.f;
+    sh[e] = MODE >= MASK_RECOMPUTE ? shift[g * 8 + e] : 0.f;
   }
   float s1[8], s2[8];
 #pragma unroll
@@ -396,8 +404,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     k1[e] = slices ? fl[0][g * 8 + e] : coef[g * 8 + e];
     k2[e] = slices ? fl[1][g * 8 + e] : coef[C + g * 8 + e];
     k3[e] = slices ? fl[2][g * 8 + e] : coef[2 * C + g * 8 + e];
-    sc[e] = MODE == MASK_RECOMPUTE ? scale[g * 8 + e] : 0.f;
-    sh[e] = MODE == MASK_RECOMPUTE ? shift[g * 8 + e] : 0.f;
+    sc[e] = MODE >= MASK_RECOMPUTE ? scale[g * 8 + e] : 0.f;
+    sh[e] = MODE >= MASK_RECOMPUTE ? shift[g * 8 + e] : 0.f;
   }
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
        v += (long long)gridDim.x * blockDim.x) {
@@ -498,10 +506,12 @@ int mpr_bn_eval_coefs(const float* gamma, const float* beta, const float* runnin
 static int launch_bn_apply(const bf16_t* xp, const float* scale, const float* shift, const bf16_t* rp, int relu,
                            bf16_t* yp, long long nvec, int C, int grid, int BLK, const float* slices, int nsl,
                            const BnFinalizeArgs& a, hipStream_t st) {
-  if (relu && rp) bn_apply_kernel<true, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
-  else if (relu) bn_apply_kernel<true, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
-  else if (rp) bn_apply_kernel<false, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
-  else bn_apply_kernel<false, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  if (relu == 2 && rp) bn_apply_kernel<2, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  else if (relu == 2) bn_apply_kernel<2, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  else if (relu && rp) bn_apply_kernel<1, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  else if (relu) bn_apply_kernel<1, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  else if (rp) bn_apply_kernel<0, true><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
+  else bn_apply_kernel<0, false><<<grid, BLK, 0, st>>>(xp, scale, shift, rp, yp, nvec, C / 8, slices, nsl, a);
   MPR_LAUNCH_CHECK("bn_apply_kernel");
   return MPR_OK;
 }
@@ -537,7 +547,7 @@ int mpr_bn_apply_fin(const void* x, const float* slices, int nsl, long long coun
                          slices, nsl, a, (hipStream_t)stream);
 }
 
-// mask_mode: 0 none, 1 relu mask from y (y > 0), 2 recompute relu mask from x*scale+shift
+// mask_mode: 0 none, 1 relu mask from y (y > 0), 2 recompute relu mask from x*scale+shift, 3 SiLU derivative at x*scale+shift
 int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                       const float* scale, const float* shift, int mask_mode, float* partials, long long rows,
                       int C, void* stream) {
@@ -549,6 +559,7 @@ int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float*
 #define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, partials, nvec, C
   if (mask_mode == MASK_NONE) bn_bwd_reduce_kernel<MASK_NONE><<<grid, block, 0, st>>>(ARGS);
   else if (mask_mode == MASK_Y) bn_bwd_reduce_kernel<MASK_Y><<<grid, block, 0, st>>>(ARGS);
+  else if (mask_mode == MASK_SILU) bn_bwd_reduce_kernel<MASK_SILU><<<grid, block, 0, st>>>(ARGS);
   else bn_bwd_reduce_kernel<MASK_RECOMPUTE><<<grid, block, 0, st>>>(ARGS);
 #undef ARGS
   MPR_LAUNCH_CHECK("bn_bwd_reduce_kernel");
@@ -576,6 +587,7 @@ int mpr_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* 
              nullptr, 0, BnFinalizeArgs{}
   if (mask_mode == MASK_NONE) bn_bwd_apply_kernel<MASK_NONE><<<grid, BLK, 0, st>>>(ARGS);
   else if (mask_mode == MASK_Y) bn_bwd_apply_kernel<MASK_Y><<<grid, BLK, 0, st>>>(ARGS);
+  else if (mask_mode == MASK_SILU) bn_bwd_apply_kernel<MASK_SILU><<<grid, BLK, 0, st>>>(ARGS);
   else bn_bwd_apply_kernel<MASK_RECOMPUTE><<<grid, BLK, 0, st>>>(ARGS);
 #undef ARGS
   MPR_LAUNCH_CHECK("bn_bwd_apply_kernel");
@@ -601,6 +613,7 @@ int mpr_bn_bwd_apply_fin(const void* dy, const void* y, const void* x, const flo
              slices, nsl, a
   if (mask_mode == MASK_NONE) bn_bwd_apply_kernel<MASK_NONE><<<grid, BLK, 0, st>>>(ARGS);
   else if (mask_mode == MASK_Y) bn_bwd_apply_kernel<MASK_Y><<<grid, BLK, 0, st>>>(ARGS);
+  else if (mask_mode == MASK_SILU) bn_bwd_apply_kernel<MASK_SILU><<<grid, BLK, 0, st>>>(ARGS);
   else bn_bwd_apply_kernel<MASK_RECOMPUTE><<<grid, BLK, 0, st>>>(ARGS);
 #undef ARGS
   MPR_LAUNCH_CHECK("bn_bwd_apply_kernel");

@@ -22,6 +22,7 @@ from .layers import BatchNormParams, _bn_coefs, _rows
 from .ops import ConvGeom, BF16, F32
 
 _SILU, _SIGMOID = 3, 4
+MASK_SILU = 3          # batchnorm.hip: dz = dy * silu'(x * scale + shift)
 
 
 # ---------------------------------------------------------------------------------------------- kernel wrappers
@@ -58,11 +59,13 @@ def dwconv_wgrad(x, dy, g, weight):
 
 
 class ConvBnFn(torch.autograd.Function):
-    """conv (kind: 'pw' implicit-GEMM | 'dw' depthwise | 'stem' few-input-channel direct) -> BatchNorm (+ residual), no
-    activation (SiLU is its own Function).  Train mode: batch statistics, running buffers updated."""
+    """conv (kind: 'pw' implicit-GEMM | 'dw' depthwise | 'stem' few-input-channel direct) -> BatchNorm (+ residual)
+    -> optional SiLU fused into the BatchNorm passes (forward: inside the apply kernel; backward: the derivative is
+    recomputed from the conv output inside both BatchNorm-backward passes).  Train mode: batch statistics, running buffers
+    updated."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, residual, mod, kind, geom):
+    def forward(ctx, x, w, gamma, beta, residual, mod, kind, geom, silu=False):
         train = mod.training
         if kind == 'pw':
             wf, wd = ops.packed_weights(w, geom, train)
@@ -74,7 +77,8 @@ class ConvBnFn(torch.autograd.Function):
             wd = None
             xc, stats = ops.stem_fwd(x, w, geom, train)
         st = _bn_coefs(stats, _rows(xc), mod, train, xc)
-        out = ops.bn_apply(xc, st, residual, False)
+        out = ops.bn_apply(xc, st, residual, 2 if silu else 0)
+        ctx.silu = silu
         ctx.train, ctx.kind, ctx.geom, ctx.st, ctx.wd = train, kind, geom, st, wd
         ctx.has_res = residual is not None
         if train:
@@ -88,7 +92,7 @@ class ConvBnFn(torch.autograd.Function):
         x, xc, w, gamma, beta = ctx.saved_tensors
         g, kind = ctx.geom, ctx.kind
         dout = dout.contiguous()
-        dxc, dgamma, dbeta, _ = ops.bn_bwd(dout, None, xc, gamma, ctx.st, ops.MASK_NONE, beta=beta)
+        dxc, dgamma, dbeta, _ = ops.bn_bwd(dout, None, xc, gamma, ctx.st, MASK_SILU if ctx.silu else ops.MASK_NONE, beta=beta)
         dx = None
         if kind == 'pw':
             dw = ops.conv_wgrad(x, dxc, g, w)
@@ -99,7 +103,7 @@ class ConvBnFn(torch.autograd.Function):
             dx = dwconv_dgrad(dxc, w, g, x.shape)
         else:
             dw = ops.stem_wgrad(x, dxc, g, w)
-        return dx, dw, dgamma, dbeta, (dout if ctx.has_res else None), None, None, None
+        return dx, dw, dgamma, dbeta, (dout if ctx.has_res else None), None, None, None, None
 
 
 class SiLUFn(torch.autograd.Function):
@@ -202,8 +206,8 @@ class _SE(nn.Module):
                                      self.conv_expand.bias)
 
 
-def _conv_bn(x, conv, bn, kind, geom, residual=None):
-    return ConvBnFn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, kind, geom)
+def _conv_bn(x, conv, bn, kind, geom, residual=None, silu=False):
+    return ConvBnFn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, kind, geom, silu)
 
 
 class DepthwiseSeparableConv(nn.Module):
@@ -221,7 +225,7 @@ class DepthwiseSeparableConv(nn.Module):
         self.g_pw = ConvGeom((cout, cin, 1, 1), 1, 0)
 
     def forward(self, x):
-        h = SiLUFn.apply(_conv_bn(x, self.conv_dw, self.bn1, 'dw', self.g_dw))
+        h = _conv_bn(x, self.conv_dw, self.bn1, 'dw', self.g_dw, silu=True)
         h = self.se(h)
         return _conv_bn(h, self.conv_pw, self.bn2, 'pw', self.g_pw, x if self.has_skip else None)
 
@@ -245,8 +249,8 @@ class InvertedResidual(nn.Module):
         self.g_pwl = ConvGeom((cout, mid, 1, 1), 1, 0)
 
     def forward(self, x):
-        h = SiLUFn.apply(_conv_bn(x, self.conv_pw, self.bn1, 'pw', self.g_pw))
-        h = SiLUFn.apply(_conv_bn(h, self.conv_dw, self.bn2, 'dw', self.g_dw))
+        h = _conv_bn(x, self.conv_pw, self.bn1, 'pw', self.g_pw, silu=True)
+        h = _conv_bn(h, self.conv_dw, self.bn2, 'dw', self.g_dw, silu=True)
         h = self.se(h)
         return _conv_bn(h, self.conv_pwl, self.bn3, 'pw', self.g_pwl, x if self.has_skip else None)
 
@@ -289,8 +293,8 @@ class EfficientNetBackbone(nn.Module):
         B, C, H, W = image.shape
         x = image.float()
         x = (x.reshape(B, H, W, 1) if C == 1 else x.permute(0, 2, 3, 1)).contiguous()
-        h = SiLUFn.apply(_conv_bn(x, self.conv_stem, self.bn1, 'stem', self.g_stem))
+        h = _conv_bn(x, self.conv_stem, self.bn1, 'stem', self.g_stem, silu=True)
         for stage in self.blocks:
             for blk in stage:
                 h = blk(h)
-        return SiLUFn.apply(_conv_bn(h, self.conv_head, self.bn2, 'pw', self.g_head))
+        return _conv_bn(h, self.conv_head, self.bn2, 'pw', self.g_head, silu=True)
