@@ -121,7 +121,13 @@ class ViTBackbone(nn.Module):
         patches = image.float().reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * P * P)
         if TF.mixed() and (C * P * P) % 8 == 0 and d % 8 == 0:
             from .transformer_mixed import LinearMixedFn
-            x = LinearMixedFn.apply(patches.contiguous(), self.patch_embed.proj.weight.view(d, -1), self.patch_embed.proj.bias)
+            # ONE persistent [d, C*P*P] view of the conv filter: the bf16 panel cache and the optimizer's repack table
+            # hang off the tensor object, a fresh view per step would rebuild both every step
+            w4 = self.patch_embed.proj.weight
+            w2 = getattr(self, '_pe_view', None)
+            if w2 is None or w2.data_ptr() != w4.data_ptr() or w2.device != w4.device:
+                w2 = self._pe_view = w4.view(d, -1)
+            x = LinearMixedFn.apply(patches.contiguous(), w2, self.patch_embed.proj.bias)
         else:
             x = linear(patches.contiguous(), self.patch_embed.proj.weight.view(d, -1), self.patch_embed.proj.bias)
         x = torch.cat((self.cls_token.expand(B, 1, d), x.view(B, gh * gw, d)), 1).contiguous()
