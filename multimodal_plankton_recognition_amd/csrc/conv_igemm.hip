@@ -747,9 +747,14 @@ extern "C" int mpr_conv_set_dgrad_parity(int on) {
 static inline void igemm_config(long long M, int Nout, int srcC, int taps, int* mode, int* BM, int* BN) {
   const bool narrow = Nout <= 64;
   if (srcC % 64 == 0 && taps <= 32 && M >= g_dma_min_rows) {
-    *mode = 1; *BN = narrow ? 64 : 128;
+    const int vw = g_variant_wide;
+    // wide outputs of big GEMMs (the transformer's qkv / MLP linears: N >= 1536, one tap): 256 x 256 tile on 16 waves --
+    // 128 FLOP per LDS-DMA byte instead of 64; measured 858 / 931 / 906 vs 780 / 761 / 719 TFLOP/s on ViT-B/16's qkv
+    // forward / fc1 forward / fc2 data gradient (scripts/bench_linear_variants.py), slower below that width (too few tiles)
+    const bool big = vw == 1 && Nout >= 1536 && M >= 8192 && taps == 1;
+    *mode = 1; *BN = narrow ? 64 : ((big || (vw >= 7 && vw <= 9 && Nout >= 256)) ? 256 : 128);
     *BM = narrow ? (g_variant_narrow == 2 ? 128 : 256)
-                 : ((g_variant_wide == 0 || g_variant_wide == 5 || g_variant_wide == 6) ? 256 : 128);
+                 : ((big || vw == 0 || vw == 5 || vw == 6 || ((vw == 7 || vw == 8) && Nout >= 256)) ? 256 : 128);
   } else {
     *mode = 0; *BM = narrow ? 256 : 128; *BN = narrow ? 64 : 128;
   }
@@ -825,7 +830,10 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
         case 4: MPR_DMA(2, 2, 4, 32); break;
         case 5: MPR_DMA(4, 2, 3, 32); break;
         case 6: MPR_DMA(4, 2, 4, 32); break;
-        default: MPR_DMA(2, 2, 2, 64); break;
+        case 7: if (BN == 256) MPR_DMA(4, 4, 2, 64); else MPR_DMA(2, 2, 2, 64); break;     // 256 x 256, 16 waves
+        case 8: if (BN == 256) MPR_DMA(4, 4, 3, 32); else MPR_DMA(2, 2, 2, 64); break;
+        case 9: if (BN == 256) MPR_DMA(2, 4, 2, 64); else MPR_DMA(2, 2, 2, 64); break;     // 128 x 256, 8 waves
+        default: if (BN == 256) MPR_DMA(4, 4, 2, 64); else MPR_DMA(2, 2, 2, 64); break;
       }
     }
 #undef MPR_DMA

@@ -355,3 +355,22 @@ def test_multi_tensor_weight_pack_equals_single_pack(shape):
         wd.fill_(7.0)
         ops.pack_registry.repack_all()
         assert torch.equal(wf, wf_ref) and torch.equal(wd, wd_ref), (shape, krsc)
+
+
+def test_wide_linear_takes_the_256x256_tile_and_matches_torch():
+    """Transformer-sized 1x1 'convolution' (M >= 8192 rows, N >= 1536 outputs): the 16-wave 256 x 256 tile, with a ragged
+    M tail and a ragged N tail, forward and data gradient against torch on identical bf16 operands."""
+    ops = _ops()
+    B, L, C, K = 40, 205, 64, 1544
+    x = bf(rnd(B, L, C, seed=21)).float()
+    w = bf(rnd(K, C, seed=22, scale=C ** -0.5)).float()
+    g = ops.ConvGeom((K, C))
+    wf, wd = ops.packed_weights(w.to(DEV), g)
+    y, _ = ops.conv_fwd(bf(x).to(DEV), wf, g, False)
+    assert_close_bf16(y, x @ w.t(), 'wide linear fwd')
+    dy = bf(rnd(B, L, K, seed=23)).float()
+    g2 = ops.ConvGeom((C, K))                      # data gradient of a K -> C linear == wide-output GEMM dy W
+    w2 = bf(rnd(C, K, seed=24, scale=K ** -0.5)).float()
+    _, wd2 = ops.packed_weights(w2.to(DEV), g2)
+    dx = ops.conv_dgrad(bf(rnd(B, L, C, seed=25)).to(DEV), wd2, g2, (B, L, K))
+    assert_close_bf16(dx, bf(rnd(B, L, C, seed=25)).float() @ w2, 'wide linear dgrad')
