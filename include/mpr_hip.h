@@ -84,6 +84,9 @@ int mpr_conv_set_wgrad_dma_min_pixels(int pixels);
 /* workgroups the split over pixels of the LDS-DMA weight-gradient kernel aims at (default 512 = one full round of
  * 2 per CU); returns the previous value */
 int mpr_conv_set_wgrad_target_wgs(int n);
+/* output tile of the LDS-DMA weight-gradient kernel on big one-tap GEMMs (transformer linears): 0 = 128 x 128 (4 waves),
+ * 1 = 256 x 256 (16 waves), 2 = 256 x 128, 3 = 128 x 256 (8 waves); returns the previous value */
+int mpr_conv_set_wgrad_tile(int v);
 /* weight gradients of 3x3 / stride 1 / pad 1 convolutions (C, K multiples of 64) run on the sliding-window kernel
  * (conv_wgrad_win.hip); 0 switches it off (tests / comparisons); returns the previous setting */
 int mpr_conv_set_wgrad_window(int on);

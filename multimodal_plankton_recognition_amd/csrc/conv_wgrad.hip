@@ -420,6 +420,12 @@ extern "C" int mpr_conv_set_wgrad_target_wgs(int n) {   // tuning knob; returns 
   g_wgrad_target_wgs = n;
   return old;
 }
+static int g_wgrad_tile = 0;
+extern "C" int mpr_conv_set_wgrad_tile(int v) {   // tuning knob (see mpr_conv_wgrad); returns the previous value
+  const int old = g_wgrad_tile;
+  g_wgrad_tile = v;
+  return old;
+}
 static unsigned long long* g_wgrad_stamps = nullptr;
 extern "C" int mpr_conv_debug_wgrad_stamps(void* buf) {
   g_wgrad_stamps = (unsigned long long*)buf;
@@ -502,8 +508,14 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   }
   if (C % 64 == 0 && K % 64 == 0 && R * S <= 31 && p.Mpix >= g_wgrad_dma_min_pix) {
     // LDS-DMA ring kernel: 64-pixel chunks, 2 workgroups per CU
-    const int WM = K <= 64 ? 1 : 2;
-    const int WN = p.Ng <= 64 ? 1 : ((C == 64 && p.Ng % 192 == 0) ? 3 : 2);
+    int WM = K <= 64 ? 1 : 2;
+    int WN = p.Ng <= 64 ? 1 : ((C == 64 && p.Ng % 192 == 0) ? 3 : 2);
+    // big one-tap GEMMs (transformer linears): larger output tiles = more FLOP per LDS-DMA byte (g_wgrad_tile: 0 off,
+    // 1 = 256 x 256 on 16 waves, 2 = 256 x 128, 3 = 128 x 256 on 8 waves)
+    if (g_wgrad_tile && R * S == 1 && K >= 512 && p.Ng >= 512 && p.Mpix >= 8192) {
+      WM = g_wgrad_tile == 3 ? 2 : 4;
+      WN = g_wgrad_tile == 2 ? 2 : 4;
+    }
     const int BM = 64 * WM, BN = 64 * WN;
     p.ntm = ceil_div(K, BM); p.ntn = ceil_div(p.Ng, BN);
     const int tiles = p.ntm * p.ntn;
@@ -526,7 +538,7 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
     static bool attr_set = false;                                                                     \
     if (!attr_set) {                                                                                  \
       hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<WM_, WN_>,                               \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                     \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_set = true;                                                                                \
     }                                                                                                 \
     conv_wgrad_dma_kernel<WM_, WN_><<<grid, 64 * WM_ * WN_, smem_, st>>>(p);                          \
@@ -536,6 +548,9 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
     else if (WM == 1 && WN == 3) MPR_WGD(1, 3);
     else if (WM == 2 && WN == 1) MPR_WGD(2, 1);
     else if (WM == 2 && WN == 2) MPR_WGD(2, 2);
+    else if (WM == 4 && WN == 4) MPR_WGD(4, 4);
+    else if (WM == 4 && WN == 2) MPR_WGD(4, 2);
+    else if (WM == 2 && WN == 4) MPR_WGD(2, 4);
     else MPR_WGD(2, 3);
 #undef MPR_WGD
     mpr_prof_end(tok, st);
