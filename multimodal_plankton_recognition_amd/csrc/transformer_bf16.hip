@@ -831,6 +831,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ host side
+// partial rows per workgroup of tf_colsum_kernel: ~16 (the kernel is a latency chain of dependent row reads), at most 128
+// workgroups per column block adding into one address
+static inline int colsum_splits(int nparts) {
+  int s = nparts / 16;
+  return s < 1 ? 1 : (s > 128 ? 128 : s);
+}
+
 static inline unsigned tb_grid(long long n) {
   long long g = (n + 255) / 256;
   return (unsigned)(g < 8192 ? (g < 1 ? 1 : g) : 8192);
@@ -890,7 +897,7 @@ int mpr_tf_ln_bwd(const void* dy16, const float* dy32, const float* s, const flo
     MPR_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * D, st));
     MPR_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * D, st));
   }
-  tf_colsum_kernel<<<dim3(ceil_div(2 * D, 256), nb >= 64 ? 16 : 1), 256, 0, st>>>(workspace, dgamma, dbeta, nb, 2 * D, D);
+  tf_colsum_kernel<<<dim3(ceil_div(2 * D, 256), colsum_splits(nb)), 256, 0, st>>>(workspace, dgamma, dbeta, nb, 2 * D, D);
   MPR_LAUNCH_CHECK("tf_colsum_kernel");
   return MPR_OK;
 }
@@ -945,7 +952,7 @@ int mpr_tf_ew_bwd(int mode, const void* dy, const void* x, const float* bias, in
   else tf_ew_bwd_kernel<2><<<grid, 256, 0, st>>>(p);
   MPR_LAUNCH_CHECK("tf_ew_bwd_kernel");
   if (dbias) {
-    tf_colsum_kernel<<<dim3(ceil_div(D, 256), slabs >= 64 ? 16 : 1), 256, 0, st>>>(workspace, dbias, dbias, slabs, D, D);
+    tf_colsum_kernel<<<dim3(ceil_div(D, 256), colsum_splits(slabs)), 256, 0, st>>>(workspace, dbias, dbias, slabs, D, D);
     MPR_LAUNCH_CHECK("tf_colsum_kernel");
   }
   return MPR_OK;
