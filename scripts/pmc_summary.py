@@ -42,13 +42,13 @@ def family(*prefixes):
     return {'launches_per_step': n, 'hbm_bytes_per_launch': b / max(n, 1), 'hbm_bytes_per_step': b}
 
 
-summary = {'tag': tag, 'workload': 'bench.py C3 step, batch 512, one MI355X', 'correction': 'read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB',
+summary = {'tag': tag, 'workload': (sys.argv[2] if len(sys.argv) > 2 else 'bench.py C3 step, batch 512, one MI355X'), 'correction': 'read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB',
            'conv_igemm_dma_kernel': family('conv_igemm_dma_kernel', 'conv_win_kernel'), 'conv_wgrad_dma_kernel': family('conv_wgrad_dma_kernel'),
            'whole_step_hbm_bytes': sum(v['read_bytes_per_step'] + v['write_bytes_per_step'] for v in out.values()),
            'kernels': out}
 json.dump(summary, open(f'profiles/{tag}_pmc_traffic.json', 'w'), indent=1)
 with open(f'profiles/{tag}_pmc_traffic.md', 'w') as f:
-    f.write(f'# HBM traffic per kernel, one C3 step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), {tag}\n\n')
+    f.write(f'# HBM traffic per kernel, one step of {summary["workload"]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), {tag}\n\n')
     f.write('read = 2 x FETCH_SIZE KiB (gfx950 wide-read correction), write = WRITE_SIZE KiB\n\n')
     f.write('| kernel | launches/step | read MB/step | write MB/step | MB/launch |\n|---|---|---|---|---|\n')
     for k, v in sorted(out.items(), key=lambda kv: -(kv[1]['read_bytes_per_step'] + kv[1]['write_bytes_per_step'])):
