@@ -6,9 +6,9 @@
 //   C[b] = alpha * op(A[b]) * op(B[b]) (+ bias) + beta * C[b],   op = identity or transpose, row-major, any ld.
 // One workgroup = 4 waves = 64x64 of C, one 32x32 MFMA tile per wave.  K advances in chunks of 32 staged
 // k-major in double-buffered LDS (so the MFMA operands -- lane -> row, lane>>5 -> k -- are conflict-free
-// ds_read_b32); the global loads of chunk t+1 are issued before the 16 MFMAs of chunk t and written to the
-// other buffer after them: one barrier per chunk.  These problems are ~0.3 GFLOP each (latency-bound), so the
-// point is to keep loads in flight, not tile reuse.
+// ds_read_b32); the global loads of chunk t+2 are issued before the 16 MFMAs of chunk t (two register sets), chunk t+1
+// is written to the other LDS buffer after them: one barrier per chunk.  These problems are ~0.3 GFLOP each
+// (latency-bound), so the point is to keep loads in flight, not tile reuse.
 #include "common.h"
 
 struct GemmF32Params {
@@ -45,21 +45,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
     if (!p.transA) { ak[i] = idx & (GF_BK - 1); am[i] = idx / GF_BK; } else { am[i] = idx & 63; ak[i] = idx >> 6; }
     if (!p.transB) { bn[i] = idx & 63; bk[i] = idx >> 6; } else { bk[i] = idx & (GF_BK - 1); bn[i] = idx / GF_BK; }
   }
-  float ra[8], rb[8];
-  auto load = [&](int k0) {
+  // two register sets: chunk t+2 is requested while chunk t is multiplied and chunk t+1 waits in the other set -- these
+  // problems run ONE workgroup per CU (64 of them for a 512 x 512 product), so nothing else hides the ~2 us of a load:
+  // with one chunk of lookahead a 514-deep product took 38 us, 17 exposed latencies
+  float ra[2][8], rb[2][8];
+  auto load = [&](int k0, float* xa, float* xb) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int gm = m0 + am[i], gk = k0 + ak[i];
-      ra[i] = (gm < p.M && gk < p.K) ? (p.transA ? A[(long long)gk * p.lda + gm] : A[(long long)gm * p.lda + gk]) : 0.f;
+      xa[i] = (gm < p.M && gk < p.K) ? (p.transA ? A[(long long)gk * p.lda + gm] : A[(long long)gm * p.lda + gk]) : 0.f;
       const int gn = n0 + bn[i], gkb = k0 + bk[i];
-      rb[i] = (gn < p.N && gkb < p.K) ? (p.transB ? B[(long long)gn * p.ldb + gkb] : B[(long long)gkb * p.ldb + gn]) : 0.f;
+      xb[i] = (gn < p.N && gkb < p.K) ? (p.transB ? B[(long long)gn * p.ldb + gkb] : B[(long long)gkb * p.ldb + gn]) : 0.f;
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, const float* xa, const float* xb) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      As[buf][ak[i]][am[i]] = ra[i];
-      Bs[buf][bk[i]][bn[i]] = rb[i];
+      As[buf][ak[i]][am[i]] = xa[i];
+      Bs[buf][bk[i]][bn[i]] = xb[i];
     }
   };
 
@@ -69,21 +72,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 
   const int nk = (p.K + GF_BK - 1) / GF_BK;
   if (nk > 0) {
-    load(0);
-    store(0);
+    load(0, ra[0], rb[0]);
+    if (nk > 1) load(GF_BK, ra[1], rb[1]);
+    store(0, ra[0], rb[0]);
   }
   __syncthreads();
-  for (int t = 0; t < nk; ++t) {
+  auto step = [&](int t, float* free_a, float* free_b, const float* next_a, const float* next_b) {
     const int cur = t & 1;
-    if (t + 1 < nk) load((t + 1) * GF_BK);
+    if (t + 2 < nk) load((t + 2) * GF_BK, free_a, free_b);          // (the set whose chunk t is already in LDS)
 #pragma unroll
-    for (int s = 0; s < GF_BK / 2; ++s) {
-      const float a = As[cur][2 * s + (lane >> 5)][wm * 32 + (lane & 31)];
-      const float b = Bs[cur][2 * s + (lane >> 5)][wn * 32 + (lane & 31)];
+    for (int s2 = 0; s2 < GF_BK / 2; ++s2) {
+      const float a = As[cur][2 * s2 + (lane >> 5)][wm * 32 + (lane & 31)];
+      const float b = Bs[cur][2 * s2 + (lane >> 5)][wn * 32 + (lane & 31)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    if (t + 1 < nk) store(cur ^ 1);
+    if (t + 1 < nk) store(cur ^ 1, next_a, next_b);
     __syncthreads();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    step(t, ra[0], rb[0], ra[1], rb[1]);
+    if (t + 1 < nk) step(t + 1, ra[1], rb[1], ra[0], rb[0]);
   }
 
   const int n = n0 + wn * 32 + (lane & 31);
