@@ -23,14 +23,14 @@ __global__ __launch_bounds__(256) void dw_pack_kernel(const float* __restrict__ 
 // y[b][p][q][c] = sum_{r,s} x[b][p*sh-ph+r][q*sw-pw+s][c] * wt[r*S+s][c]
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const uint4* __restrict__ x, const float* __restrict__ w,
                                                      uint4* __restrict__ y, const DwGeom g) {
-  const int G = g.C / 8;
-  const long long total = (long long)g.B * g.P * g.Q * G;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+  const uint32_t G = g.C / 8;
+  const uint32_t total = (uint32_t)g.B * g.P * g.Q * G;            // (< 2^31: checked by the host)
+  for (uint32_t idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int cg = (int)(idx % G);
-    long long pix = idx / G;
-    const int q = (int)(pix % g.Q);
-    pix /= g.Q;
-    const int p = (int)(pix % g.P), b = (int)(pix / g.P);
+    uint32_t pix = idx / G;
+    const int q = (int)(pix % (uint32_t)g.Q);
+    pix /= (uint32_t)g.Q;
+    const int p = (int)(pix % (uint32_t)g.P), b = (int)(pix / (uint32_t)g.P);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -56,14 +56,14 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const uint4* __restrict__ x
 // dx[b][h][w][c] = sum_{r,s : (h+ph-r) % sh == 0, ...} dy[b][(h+ph-r)/sh][(w+pw-s)/sw][c] * w[c][r][s]
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const uint4* __restrict__ dy, const float* __restrict__ w,
                                                        uint4* __restrict__ dx, const DwGeom g) {
-  const int G = g.C / 8;
-  const long long total = (long long)g.B * g.H * g.W * G;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+  const uint32_t G = g.C / 8;
+  const uint32_t total = (uint32_t)g.B * g.H * g.W * G;
+  for (uint32_t idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int cg = (int)(idx % G);
-    long long pix = idx / G;
-    const int ww = (int)(pix % g.W);
-    pix /= g.W;
-    const int h = (int)(pix % g.H), b = (int)(pix / g.H);
+    uint32_t pix = idx / G;
+    const int ww = (int)(pix % (uint32_t)g.W);
+    pix /= (uint32_t)g.W;
+    const int h = (int)(pix % (uint32_t)g.H), b = (int)(pix / (uint32_t)g.H);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const uint4* __restrict__
   }
 }
 
-// partial weight gradients of one slab of output pixels and ONE filter row r = blockIdx.z: part[slab][tap][C].
+// partial weight gradients of one slab of output pixels and ONE filter row r: part[slab][tap][C].
 // Block = Gp channel groups (power of two >= C/8, <= 256) x 256/Gp pixel lanes; a thread keeps the S <= 5 taps of the row for
 // its 8 channels in registers (dy loaded once per pixel, x once per tap), lanes reduced through LDS.
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy,
@@ -98,10 +98,14 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const uint4* __restrict__
   __shared__ float red[256][41];
   const int G = g.C / 8, RS = g.R * g.S, nl = 256 / Gp;
   const int cl = threadIdx.x % Gp, rl = threadIdx.x / Gp;
-  const int cg = blockIdx.x * Gp + cl, r = blockIdx.z;
-  const long long npix = (long long)g.B * g.P * g.Q;
-  const long long p0 = (long long)blockIdx.y * pix_per_slab;
-  long long p1 = p0 + pix_per_slab;
+  // the R filter rows of one slab are neighbours in dispatch order (x = column block * R + r): they run at the same time and
+  // the slab's x / dy lines are fetched from HBM once and found in the Infinity Cache / L2 by the others, instead of the
+  // whole activation being re-read by R separate sweeps
+  const int r = blockIdx.x % g.R;
+  const int cg = (blockIdx.x / g.R) * Gp + cl;
+  const uint32_t npix = (uint32_t)g.B * g.P * g.Q;
+  const uint32_t p0 = blockIdx.y * (uint32_t)pix_per_slab;
+  uint32_t p1 = p0 + pix_per_slab;
   if (p1 > npix) p1 = npix;
   float acc[5][8];
 #pragma unroll
@@ -109,10 +113,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const uint4* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[s][e] = 0.f;
   if (cg < G) {
-    for (long long pix = p0 + rl; pix < p1; pix += nl) {
-      const int q = (int)(pix % g.Q);
-      const long long bp = pix / g.Q;
-      const int p = (int)(bp % g.P), b = (int)(bp / g.P);
+    for (uint32_t pix = p0 + rl; pix < p1; pix += nl) {
+      const int q = (int)(pix % (uint32_t)g.Q);
+      const uint32_t bp = pix / (uint32_t)g.Q;
+      const int p = (int)(bp % (uint32_t)g.P), b = (int)(bp / (uint32_t)g.P);
       const int h = p * g.sh - g.ph + r;
       if (h < 0 || h >= g.H) continue;
       float d[8];
@@ -238,7 +242,8 @@ static inline bool dw_geom(DwGeom* g, int B, int H, int W, int C, int R, int S, 
   g->B = B; g->H = H; g->W = W; g->C = C; g->R = R; g->S = S; g->sh = sh; g->sw = sw; g->ph = ph; g->pw = pw;
   g->P = (H + 2 * ph - R) / sh + 1;
   g->Q = (W + 2 * pw - S) / sw + 1;
-  return B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && g->P > 0 && g->Q > 0;
+  return B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && R > 0 && S > 0 && sh > 0 && sw > 0 && g->P > 0 && g->Q > 0 &&
+         (long long)B * H * W * (C / 8) < (1ll << 31) && (long long)B * g->P * g->Q * (C / 8) < (1ll << 31);   // 32-bit indices
 }
 
 static inline int dw_pix_per_slab(long long npix) {      // at most 1024 slabs of at least 256 pixels
@@ -284,7 +289,7 @@ int mpr_dwconv_wgrad(const void* x, const void* dy, float* dw, float* workspace,
   hipStream_t st = (hipStream_t)stream;
   MPR_REQUIRE(S <= 5 && R <= 65535, "mpr_dwconv_wgrad: filter rows of at most 5 taps (S=%d)", S);
   const int gp = se_gp(C);
-  dw_wgrad_kernel<<<dim3(ceil_div(C / 8, gp), slabs, R), 256, 0, st>>>((const uint4*)x, (const uint4*)dy, workspace, g, pps, gp);
+  dw_wgrad_kernel<<<dim3(ceil_div(C / 8, gp) * R, slabs), 256, 0, st>>>((const uint4*)x, (const uint4*)dy, workspace, g, pps, gp);
   MPR_LAUNCH_CHECK("dw_wgrad_kernel");
   if (!accumulate) MPR_HIP(hipMemsetAsync(dw, 0, sizeof(float) * R * S * C, st));
   dw_wgrad_reduce_kernel<<<dim3(ceil_div(R * S * C, 256), slabs >= 32 ? 16 : 1), 256, 0, st>>>(workspace, dw, slabs, R * S, C);
