@@ -156,6 +156,8 @@ ASYNC_WGRAD = os.environ.get('MPR_ASYNC_WGRAD', '1') != '0'
 _arena_streams = {}        # raw stream handle -> torch stream object
 _wgrad_side = {}           # raw handle of a compute stream -> its weight-gradient side stream
 _join_queued = [False]
+KEEPALIVE_WGRAD_OPERANDS = os.environ.get('MPR_WGRAD_KEEPALIVE', '1') != '0'
+_wgrad_keepalive = []      # operands of weight gradients still queued on a side stream (released by the join)
 
 
 def _note_arena_stream(dev, stream=None):
@@ -177,6 +179,7 @@ def join_gradient_streams():
     for h, s in _arena_streams.items():
         if h != cur.cuda_stream:
             cur.wait_stream(s)
+    _wgrad_keepalive.clear()
 
 
 def _wgrad_stream(dev):
@@ -305,9 +308,18 @@ def _conv_wgrad(x, dy, g, weight, B, H, W, C):
                 cur, side = _wgrad_stream(x.device.index)
                 side.wait_stream(cur)
                 _wgrad_call(x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail, stream_handle=side.cuda_stream)
-                x.record_stream(side)           # the allocator must not recycle the operands under the side stream
-                dy.record_stream(side)
                 _note_arena_stream(x.device.index, side)
+                # the allocator must not recycle the operands under the side stream.  Tensor.record_stream would do, but a
+                # block freed with a pending foreign-stream use sits in limbo until that (low-priority, lagging) stream
+                # passes it, and the allocator hands out fresh memory meanwhile: 52 GB reserved for a 6 GB working set,
+                # growing slowly.  Holding the two tensors until the end-of-backward join (every later user of their
+                # memory is then ordered behind the side stream) costs ~2.7 GB of gradients kept a little longer:
+                # 7.8 GB reserved.  (Outside a backward pass no join is queued: record_stream.)
+                if KEEPALIVE_WGRAD_OPERANDS and _join_queued[0]:
+                    _wgrad_keepalive.append((x, dy))
+                else:
+                    x.record_stream(side)
+                    dy.record_stream(side)
             else:
                 _wgrad_call(x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail)
             return None
