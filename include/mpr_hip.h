@@ -243,7 +243,8 @@ int mpr_tf_ew_bwd(int mode, const void* dy, const void* x /* mode 1 */, const fl
                   unsigned seed, void* dx, float* dbias, float* workspace /* needed iff dbias */, int rows, int D,
                   void* stream);
 /* fused multi-head self-attention on a packed bf16 qkv [B][T][3*heads*head_dim] (torch MHA / timm layout) whose
- * in-projection bias is added while the operands are loaded; key-padding mask [B][T] bytes; T <= 256, head_dim 32 | 64.
+ * in-projection bias is added while the operands are loaded; key-padding mask [B][T] bytes; head_dim 64 with T <= 256
+ * or head_dim 32 with T <= 288 (mpr_attn_supported).
  * out bf16 [B][T][heads*head_dim]; lse fp32 [B*heads][T] is kept for backward; delta: [B*heads][T] scratch */
 int mpr_attn_supported(int T, int head_dim);
 int mpr_attn_fwd(const void* qkv, const float* bias /* may be NULL */, const void* key_padding_mask /* may be NULL */,

@@ -452,29 +452,29 @@ __device__ __forceinline__ uint4 add_bias8(const uint4& v, const float* bias) {
 // row image (row stride RS bytes) and / or the transposed image ([HD][Tp], row stride TS bytes).
 template <int HD>
 struct StageRegs {
-  static constexpr int G = HD / 8, IT = 256 * G / 512;      // Tp <= 256: at most IT rounds of 512 threads
+  static constexpr int G = HD / 8, IT = G / 2;      // 64 NB threads cover 32 NB rows x G chunks in G / 2 rounds
   uint4 v[IT];
 };
 
-template <int HD>
+template <int HD, int NT>
 __device__ __forceinline__ void stage_load(StageRegs<HD>& r, const uint16_t* __restrict__ src, size_t ld, int T) {
   constexpr int G = HD / 8;
 #pragma unroll
   for (int it = 0; it < StageRegs<HD>::IT; ++it) {
-    const int idx = threadIdx.x + 512 * it;
+    const int idx = threadIdx.x + NT * it;
     const int t = idx / G, g = idx - t * G;
     r.v[it] = make_uint4(0, 0, 0, 0);
     if (t < T) r.v[it] = *reinterpret_cast<const uint4*>(src + (size_t)t * ld + 8 * g);
   }
 }
 
-template <int HD>
+template <int HD, int NT>
 __device__ __forceinline__ void stage_store(const StageRegs<HD>& r, const float* __restrict__ bias, int T, int Tp,
                                             unsigned char* rows, int RS, unsigned char* trans, int TS) {
   constexpr int G = HD / 8;
 #pragma unroll
   for (int it = 0; it < StageRegs<HD>::IT; ++it) {
-    const int idx = threadIdx.x + 512 * it;
+    const int idx = threadIdx.x + NT * it;
     const int t = idx / G, g = idx - t * G;
     if (t >= Tp) continue;
     const uint4 w = t < T ? add_bias8(r.v[it], bias ? bias + 8 * g : nullptr) : r.v[it];
@@ -501,8 +501,8 @@ __device__ __forceinline__ bf16x8 acc_frag(const float* v) {   // 8 accumulator 
   return as_frag(pack8(v));
 }
 
-template <int HD>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
+template <int HD, int NB>
+__global__ __launch_bounds__(64 * NB) void attn_fwd_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int RS = HD * 2 + 16, NC = HD / 16, ND = HD / 32;
@@ -516,21 +516,21 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const int q = 32 * w + r, qc = q < p.T ? q : p.T - 1;
   StageRegs<HD> rk, rv;
-  stage_load<HD>(rk, base + dm, d3, p.T);
-  stage_load<HD>(rv, base + 2 * dm, d3, p.T);
+  stage_load<HD, 64 * NB>(rk, base + dm, d3, p.T);
+  stage_load<HD, 64 * NB>(rv, base + 2 * dm, d3, p.T);
   uint4 qraw[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) qraw[c] = *reinterpret_cast<const uint4*>(base + (size_t)qc * d3 + 16 * c + 8 * hh);
-  stage_store<HD>(rk, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, nullptr, 0);
-  stage_store<HD>(rv, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, nullptr, 0, Vt, TS);
+  stage_store<HD, 64 * NB>(rk, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, nullptr, 0);
+  stage_store<HD, 64 * NB>(rv, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, nullptr, 0, Vt, TS);
   __syncthreads();
   if (w >= nblk) return;
   bf16x8 qf[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) qf[c] = as_frag(add_bias8(qraw[c], p.bias ? p.bias + h * HD + 16 * c + 8 * hh : nullptr));
-  f32x16 acc[8];
+  f32x16 acc[NB];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NB; ++j) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     if (j < nblk) {
@@ -547,9 +547,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
   // c = scale * log2(e) as one FMA + v_exp_f32; the 1 / sum normalisation moves behind the P V product.
   const unsigned char* const mrow = p.mask ? p.mask + (size_t)b * p.T : nullptr;
   // per key block, bit e of bad[j] = accumulator register e holds an invalid key (tail of the last block / padding mask)
-  uint32_t bad[8];
+  uint32_t bad[NB];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NB; ++j) {
     bad[j] = 0;
     if (j < nblk && (mrow || j == nblk - 1)) {
 #pragma unroll
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
   }
   float m = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < NB; ++j)
     if (j < nblk) {
 #pragma unroll
       for (int e = 0; e < 16; ++e)
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
   const float c2 = p.scale * 1.4426950408889634f, mc = -m * c2;
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < NB; ++j)
     if (j < nblk) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < NB; ++j)
     if (j < nblk) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -632,8 +632,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnParams p) {
 }
 
 // backward, part 1 (query on the lane): delta = rowsum(dO * O), dQ = dS K
-template <int HD>
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnParams p) {
+template <int HD, int NB>
+__global__ __launch_bounds__(64 * NB) void attn_bwd_dq_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int RS = HD * 2 + 16, NC = HD / 16, ND = HD / 32;
@@ -650,8 +650,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnParams p) {
   const uint16_t* const dorow = p.dout + ((size_t)b * p.T + qc) * dm + h * HD;
   const uint16_t* const orow = p.out + ((size_t)b * p.T + qc) * dm + h * HD;
   StageRegs<HD> rk, rv;
-  stage_load<HD>(rk, base + dm, d3, p.T);
-  stage_load<HD>(rv, base + 2 * dm, d3, p.T);
+  stage_load<HD, 64 * NB>(rk, base + dm, d3, p.T);
+  stage_load<HD, 64 * NB>(rv, base + 2 * dm, d3, p.T);
   uint4 qraw[NC], dvraw[NC], ovraw[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnParams p) {
     ovraw[c] = *reinterpret_cast<const uint4*>(orow + 16 * c + 8 * hh);
   }
   const float lse = p.lse[(size_t)blockIdx.x * p.T + qc];
-  stage_store<HD>(rk, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, Kt, TS);
-  stage_store<HD>(rv, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, Vs, RS, nullptr, 0);
+  stage_store<HD, 64 * NB>(rk, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, Kt, TS);
+  stage_store<HD, 64 * NB>(rv, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, Vs, RS, nullptr, 0);
   __syncthreads();
   if (w >= nblk) return;
   bf16x8 qf[NC], dof[NC];
@@ -733,8 +733,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnParams p) {
 }
 
 // backward, part 2 (key on the lane): dV^T = dO^T P, dK^T = Q^T dS
-template <int HD>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttnParams p) {
+template <int HD, int NB>
+__global__ __launch_bounds__(64 * NB) void attn_bwd_dkv_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int RS = HD * 2 + 16, NC = HD / 16, ND = HD / 32;
@@ -752,20 +752,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttnParams p) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const int key = 32 * w + r, kc = key < p.T ? key : p.T - 1;
   StageRegs<HD> rq, ro;
-  stage_load<HD>(rq, base, d3, p.T);
-  stage_load<HD>(ro, p.dout + (size_t)b * p.T * dm + h * HD, dm, p.T);
+  stage_load<HD, 64 * NB>(rq, base, d3, p.T);
+  stage_load<HD, 64 * NB>(ro, p.dout + (size_t)b * p.T * dm + h * HD, dm, p.T);
   uint4 kraw[NC], vraw[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     kraw[c] = *reinterpret_cast<const uint4*>(base + dm + (size_t)kc * d3 + 16 * c + 8 * hh);
     vraw[c] = *reinterpret_cast<const uint4*>(base + 2 * dm + (size_t)kc * d3 + 16 * c + 8 * hh);
   }
-  for (int t = threadIdx.x; t < Tp; t += 512) {
+  for (int t = threadIdx.x; t < Tp; t += 64 * NB) {
     lse_s[t] = t < p.T ? -1.4426950408889634f * p.lse[(size_t)blockIdx.x * p.T + t] : 0.f;     // (-lse * log2 e)
     del_s[t] = t < p.T ? p.delta[(size_t)blockIdx.x * p.T + t] : 0.f;
   }
-  stage_store<HD>(rq, p.bias ? p.bias + h * HD : nullptr, p.T, Tp, Qs, RS, Qt, TS);
-  stage_store<HD>(ro, nullptr, p.T, Tp, Os, RS, Ot, TS);
+  stage_store<HD, 64 * NB>(rq, p.bias ? p.bias + h * HD : nullptr, p.T, Tp, Qs, RS, Qt, TS);
+  stage_store<HD, 64 * NB>(ro, nullptr, p.T, Tp, Os, RS, Ot, TS);
   __syncthreads();
   if (w >= nblk) return;
   const bool key_valid = key < p.T && !(p.mask && p.mask[(size_t)b * p.T + kc]);
@@ -958,23 +958,29 @@ int mpr_tf_ew_bwd(int mode, const void* dy, const void* x, const float* bias, in
   return MPR_OK;
 }
 
-int mpr_attn_supported(int T, int head_dim) { return T >= 1 && T <= 256 && (head_dim == 32 || head_dim == 64); }
+// T <= 256 (8 waves, one 32-token block each); head size 32 also T <= 288 on 9 waves (LDS of the dK/dV kernel is the limit)
+int mpr_attn_supported(int T, int head_dim) {
+  return T >= 1 && ((head_dim == 64 && T <= 256) || (head_dim == 32 && T <= 288));
+}
 
 int mpr_attn_fwd(const void* qkv, const float* bias, const void* key_padding_mask, void* out, float* lse, int B, int T,
                  int heads, int head_dim, float scale, float p_drop, unsigned seed, void* stream) {
   MPR_REQUIRE(qkv && out && lse && B > 0 && heads > 0, "mpr_attn_fwd: bad arguments");
-  MPR_REQUIRE(mpr_attn_supported(T, head_dim), "mpr_attn_fwd: T <= 256 and head size 32 or 64 only (T=%d, head=%d)", T, head_dim);
+  MPR_REQUIRE(mpr_attn_supported(T, head_dim), "mpr_attn_fwd: head size 64 with T <= 256 or head size 32 with T <= 288 only (T=%d, head=%d)", T, head_dim);
   AttnParams p = {(const uint16_t*)qkv, bias, (const unsigned char*)key_padding_mask, (uint16_t*)out, lse, nullptr, nullptr,
                   nullptr, B, T, heads, scale, p_drop, seed};
   const int Tp = (T + 31) / 32 * 32;
   const size_t lds = (size_t)Tp * (head_dim * 2 + 16) + (size_t)head_dim * (Tp * 2 + 8);
   hipStream_t st = (hipStream_t)stream;
   if (head_dim == 64) {
-    if (int rc = set_lds(attn_fwd_kernel<64>, lds)) return rc;
-    attn_fwd_kernel<64><<<B * heads, 512, lds, st>>>(p);
+    if (int rc = set_lds(attn_fwd_kernel<64, 8>, lds)) return rc;
+    attn_fwd_kernel<64, 8><<<B * heads, 512, lds, st>>>(p);
+  } else if (T <= 256) {
+    if (int rc = set_lds(attn_fwd_kernel<32, 8>, lds)) return rc;
+    attn_fwd_kernel<32, 8><<<B * heads, 512, lds, st>>>(p);
   } else {
-    if (int rc = set_lds(attn_fwd_kernel<32>, lds)) return rc;
-    attn_fwd_kernel<32><<<B * heads, 512, lds, st>>>(p);
+    if (int rc = set_lds(attn_fwd_kernel<32, 9>, lds)) return rc;
+    attn_fwd_kernel<32, 9><<<B * heads, 576, lds, st>>>(p);
   }
   MPR_LAUNCH_CHECK("attn_fwd_kernel");
   return MPR_OK;
@@ -984,7 +990,7 @@ int mpr_attn_bwd(const void* qkv, const float* bias, const void* key_padding_mas
                  const float* lse, float* delta, void* dqkv, int B, int T, int heads, int head_dim, float scale, float p_drop,
                  unsigned seed, void* stream) {
   MPR_REQUIRE(qkv && out && dout && lse && delta && dqkv && B > 0 && heads > 0, "mpr_attn_bwd: bad arguments");
-  MPR_REQUIRE(mpr_attn_supported(T, head_dim), "mpr_attn_bwd: T <= 256 and head size 32 or 64 only (T=%d, head=%d)", T, head_dim);
+  MPR_REQUIRE(mpr_attn_supported(T, head_dim), "mpr_attn_bwd: head size 64 with T <= 256 or head size 32 with T <= 288 only (T=%d, head=%d)", T, head_dim);
   AttnParams p = {(const uint16_t*)qkv, bias, (const unsigned char*)key_padding_mask, (uint16_t*)out, (float*)lse,
                   (const uint16_t*)dout, delta, (uint16_t*)dqkv, B, T, heads, scale, p_drop, seed};
   const int Tp = (T + 31) / 32 * 32;
@@ -993,15 +999,20 @@ int mpr_attn_bwd(const void* qkv, const float* bias, const void* key_padding_mas
   const size_t lds_kv = 2 * Tp * rs + 2 * head_dim * ts + 2 * Tp * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (head_dim == 64) {
-    if (int rc = set_lds(attn_bwd_dq_kernel<64>, lds_q)) return rc;
-    if (int rc = set_lds(attn_bwd_dkv_kernel<64>, lds_kv)) return rc;
-    attn_bwd_dq_kernel<64><<<B * heads, 512, lds_q, st>>>(p);
-    attn_bwd_dkv_kernel<64><<<B * heads, 512, lds_kv, st>>>(p);
+    if (int rc = set_lds(attn_bwd_dq_kernel<64, 8>, lds_q)) return rc;
+    if (int rc = set_lds(attn_bwd_dkv_kernel<64, 8>, lds_kv)) return rc;
+    attn_bwd_dq_kernel<64, 8><<<B * heads, 512, lds_q, st>>>(p);
+    attn_bwd_dkv_kernel<64, 8><<<B * heads, 512, lds_kv, st>>>(p);
+  } else if (T <= 256) {
+    if (int rc = set_lds(attn_bwd_dq_kernel<32, 8>, lds_q)) return rc;
+    if (int rc = set_lds(attn_bwd_dkv_kernel<32, 8>, lds_kv)) return rc;
+    attn_bwd_dq_kernel<32, 8><<<B * heads, 512, lds_q, st>>>(p);
+    attn_bwd_dkv_kernel<32, 8><<<B * heads, 512, lds_kv, st>>>(p);
   } else {
-    if (int rc = set_lds(attn_bwd_dq_kernel<32>, lds_q)) return rc;
-    if (int rc = set_lds(attn_bwd_dkv_kernel<32>, lds_kv)) return rc;
-    attn_bwd_dq_kernel<32><<<B * heads, 512, lds_q, st>>>(p);
-    attn_bwd_dkv_kernel<32><<<B * heads, 512, lds_kv, st>>>(p);
+    if (int rc = set_lds(attn_bwd_dq_kernel<32, 9>, lds_q)) return rc;
+    if (int rc = set_lds(attn_bwd_dkv_kernel<32, 9>, lds_kv)) return rc;
+    attn_bwd_dq_kernel<32, 9><<<B * heads, 576, lds_q, st>>>(p);
+    attn_bwd_dkv_kernel<32, 9><<<B * heads, 576, lds_kv, st>>>(p);
   }
   MPR_LAUNCH_CHECK("attn_bwd kernels");
   return MPR_OK;

@@ -31,7 +31,7 @@ def supported(T, head_dim):
 def _check(T, d, heads):
     if d % heads or not supported(T, d // heads) or d % 8 or d > 1024:
         raise NotImplementedError(
-            f'bf16-mixed transformer path: needs T <= 256 tokens, head size 32 or 64 and d_model <= 1024 '
+            f'bf16-mixed transformer path: needs head size 64 with T <= 256 tokens or head size 32 with T <= 288, and d_model <= 1024 '
             f'(got T={T}, d_model={d}, heads={heads}); run this model with precision 32 (exact-fp32 kernels)')
 
 
