@@ -424,6 +424,17 @@ def _prereduce(parts, nsplit=64, limit=512):
 # are pre-reduced to FIN_SLICES rows and every workgroup of the apply kernel finishes them itself.
 FIN_IN_CONSUMER = os.environ.get('MPR_FIN_IN_CONSUMER', '1') != '0'
 FIN_SLICES = 8
+# short partial lists of narrow layers (rows x C floats per sum <= this) are handed to the consumer as they are: the
+# pre-reduction launch costs more than every apply workgroup summing <= 16 KB itself (the profile branch's 1-D layers:
+# 14..112 partial rows of 256..32 channels -- ~45 fewer launches per step on that latency-bound stream)
+FIN_DIRECT_FLOATS = int(os.environ.get('MPR_FIN_DIRECT_FLOATS', '4096'))
+
+
+def _consumer_slices(parts):
+    n, _, C = parts.shape
+    if n * C <= FIN_DIRECT_FLOATS:
+        return parts
+    return _prereduce(parts, FIN_SLICES, FIN_SLICES)
 
 
 class BNState:
@@ -449,7 +460,7 @@ def bn_coefs(stats, count, bn, train, x=None, defer=False):
         st.mean = torch.empty(C, dtype=F32, device=dev)
         st.invstd = torch.empty(C, dtype=F32, device=dev)
         if defer and FIN_IN_CONSUMER and C <= 512:
-            st.pending = (_prereduce(stats, FIN_SLICES, FIN_SLICES), count, bn)
+            st.pending = (_consumer_slices(stats), count, bn)
         elif FUSED_FINALIZE and stats.shape[0] > 512:
             # long partial list: pre-reduction and finalize in one launch (the last workgroup finalizes)
             slices = torch.empty(64, 2, C, dtype=F32, device=dev)
@@ -515,7 +526,7 @@ def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False, beta=None):
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
     if FIN_IN_CONSUMER and C <= 512:
-        slices = _prereduce(parts, FIN_SLICES, FIN_SLICES)
+        slices = _consumer_slices(parts)
         N.call('mpr_bn_bwd_apply_fin', dy, y, x, slices, slices.shape[0], rows, gamma.detach(), st.mean, st.invstd,
                dgamma, dbeta, acc, st.scale, st.shift, mask_mode, dx, dz, rows, C)
         return dx, (dgamma if ret else None), (dbeta if ret else None), dz

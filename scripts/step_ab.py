@@ -30,8 +30,9 @@ for rep in range(2):
     for name, setup in [('default', lambda: None),
                         ('one stream for both encoders', lambda: setattr(model, 'two_streams', False)),
                         ('weight gradients in-stream', lambda: setattr(ops, 'ASYNC_WGRAD', False)),
+                        ('BN partial lists always pre-reduced', lambda: setattr(ops, 'FIN_DIRECT_FLOATS', 0)),
                         ('both off', lambda: (setattr(model, 'two_streams', False), setattr(ops, 'ASYNC_WGRAD', False)))]:
-        model.two_streams, ops.ASYNC_WGRAD = True, True
+        model.two_streams, ops.ASYNC_WGRAD, ops.FIN_DIRECT_FLOATS = True, True, 4096
         setup()
         print(f'{name:32s} {timed():6.2f} ms/step', flush=True)
 model.two_streams, ops.ASYNC_WGRAD = True, True
