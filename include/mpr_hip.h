@@ -228,6 +228,7 @@ int mpr_tf_add_ln_fwd(const float* x /* NULL: zeros */, const void* r /* may be 
                       float* s_out /* may be NULL */, float* y32 /* may be NULL */, void* y16 /* may be NULL */,
                       float* mean, float* rstd, int rows, int D, void* stream);
 int mpr_tf_ln_bwd_workspace_floats(int rows, int D);
+int mpr_tf_set_ln_bwd_rows(int rows);   /* rows per workgroup of mpr_tf_ln_bwd (tuning knob, default 32); returns the previous value */
 /* ds = dLN/ds of the gradient (dy16 bf16 [+ dy32 fp32]) (+ dskip); dgamma / dbeta assigned or accumulated; D <= 1024 */
 int mpr_tf_ln_bwd(const void* dy16 /* may be NULL */, const float* dy32 /* may be NULL */, const float* s, const float* gamma,
                   const float* mean, const float* rstd, const float* dskip /* may be NULL */, float* ds, float* dgamma,

@@ -876,7 +876,15 @@ int mpr_tf_add_ln_fwd(const float* x, const void* r, const float* rbias, float p
   return MPR_OK;
 }
 
-#define TF_LN_BWD_ROWS 32
+// rows per workgroup of the LayerNorm backward (4 waves walk them): fewer rows = more workgroups in flight for a pass that is
+// bound by the latency of its row-by-row reductions, more partial rows for tf_colsum_kernel (tuning knob)
+static int g_ln_bwd_rows = 32;
+int mpr_tf_set_ln_bwd_rows(int rows) {
+  const int old = g_ln_bwd_rows;
+  if (rows >= 4) g_ln_bwd_rows = rows;
+  return old;
+}
+#define TF_LN_BWD_ROWS g_ln_bwd_rows
 int mpr_tf_ln_bwd_workspace_floats(int rows, int D) { return 2 * D * ceil_div(rows, TF_LN_BWD_ROWS); }
 
 int mpr_tf_ln_bwd(const void* dy16, const float* dy32, const float* s, const float* gamma, const float* mean,
