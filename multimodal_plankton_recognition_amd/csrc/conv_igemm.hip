@@ -650,9 +650,30 @@ __global__ void conv_pack_weights_kernel(const PackEntry e) {
   pack_one<false>(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
+// Refresh of an EXISTING forward panel whose filter rows are contiguous in memory ([K][R][S][C] channels-last filters,
+// nn.Linear weights): row k of the panel is a straight cast of R*S*C contiguous floats -- 8 elements per thread, one
+// division per 8 elements, 16-byte stores.  The zero padding (rows >= K, columns >= R*S*C) was written by the first pack
+// (mpr_conv_pack_weights_strided) and is left alone, as is the data-gradient panel's.
+__device__ __forceinline__ void pack_fwd_rows_vec(const PackEntry& e, int first, int step) {
+  const int K = (int)e.K, KgF = (int)(e.R * e.S * e.C), KgFpad = (KgF + 63) / 64 * 64, G = KgF / 8;
+  for (int i = first; i < K * G; i += step) {
+    const int k = i / G, g = i - k * G;
+    const float4* src = reinterpret_cast<const float4*>(e.w + (size_t)k * e.sk + g * 8);
+    const float4 a = src[0], b = src[1];
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    *reinterpret_cast<uint4*>(e.wf + (size_t)k * KgFpad + g * 8) = pack8(f);
+  }
+}
+
 __global__ __launch_bounds__(256) void conv_pack_weights_multi_kernel(const PackEntry* __restrict__ table) {
   const PackEntry e = table[blockIdx.y];
-  pack_one<true>(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  const bool rows_contiguous = e.sc == 1 && e.C % 8 == 0 && (e.sk * 4) % 16 == 0 &&
+                               ((e.R * e.S == 1) || (e.ss == e.C && e.sr == e.S * e.C));
+  if (rows_contiguous) {
+    pack_fwd_rows_vec(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  } else {
+    pack_one<true>(e, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  }
   if (e.wd) pack_wd_tiled(e);
 }
 
