@@ -178,3 +178,51 @@ def make_multi_collate(model, buckets):
         out['buckets'] = buckets
         return out
     return multi_collate
+
+
+# ------------------------------------------------------------------------------------------------ cached dataset (GPU augmentation)
+class CachedMultiSet(Dataset):
+    """MultiSet whose samples carry only the DETERMINISTIC part of the transforms (``augment.cache_image`` /
+    ``cache_profile``: scale-bar crop, Lanczos resize to the cached square, grayscale bytes; raw profile counts), computed
+    on first access and kept: the random part runs on the device per step (``augment.DevicePipeline``).
+    ``train=True`` caches images at ceil(1.05 T) (room for the random crop), ``train=False`` at T (test transform)."""
+
+    def __init__(self, annotation_path, target_size=224, train=True):
+        import pandas as pd
+        annotation_path = Path(annotation_path)
+        self.parent = annotation_path.parent
+        self.table = pd.read_csv(annotation_path)
+        self.class_names = np.unique(self.table['class'])
+        self.T, self.train = target_size, train
+        self._cache = {}
+
+    def __len__(self):
+        return len(self.table)
+
+    def __getitem__(self, index):
+        hit = self._cache.get(index)
+        if hit is None:
+            from PIL import Image
+            from .augment import cache_image, cache_profile
+            image = Image.open(self.parent / self.table.image[index]).convert('RGB')
+            profile = np.loadtxt(self.parent / self.table.profile[index], delimiter=',', skiprows=1)
+            side = self.T if not self.train else None
+            hit = self._cache[index] = {
+                'image_u8': cache_image(image, self.T) if side is None else cache_image(image, self.T, side=side),
+                'profile_raw': cache_profile(profile), 'label': self.table['class'][index],
+                'image_shape': torch.tensor(image.size[::-1]),                     # pre-crop (H, W), src/data.py:46
+                'profile_length': torch.tensor([profile.shape[0]])}
+        return hit
+
+
+def cached_collate(batch):
+    """Stack the cached fields: image bytes [B, S, S], zero-padded raw profiles [B, Lmax, C] + their lengths."""
+    raws = [b['profile_raw'] for b in batch]
+    lmax = max(r.shape[0] for r in raws)
+    raw = torch.zeros(len(batch), lmax, raws[0].shape[1])
+    for i, r in enumerate(raws):
+        raw[i, :r.shape[0]] = r
+    return {'image_u8': torch.stack([b['image_u8'] for b in batch]), 'profile_raw': raw,
+            'raw_len': torch.tensor([r.shape[0] for r in raws], dtype=torch.int32),
+            'image_shape': torch.stack([b['image_shape'] for b in batch]),
+            'profile_len': torch.stack([b['profile_length'] for b in batch])}

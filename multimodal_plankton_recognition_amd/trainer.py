@@ -96,7 +96,8 @@ def load_from_checkpoint(model_cls, path, map_location='cpu', **override):
 class Trainer:
     def __init__(self, logger=None, callbacks=(), max_epochs=1000, min_epochs=0, accumulate_grad_batches=1,
                  precision=None, val_check_interval=None, check_val_every_n_epoch=1, log_every_n_steps=50,
-                 max_steps=-1, limit_train_batches=None, limit_val_batches=None, device=None, **unused):
+                 max_steps=-1, limit_train_batches=None, limit_val_batches=None, device=None, batch_transform=None,
+                 **unused):
         self.logger, self.callbacks = logger, list(callbacks)
         self.max_epochs, self.min_epochs = max_epochs, min_epochs or 0
         self.accumulate = max(1, int(accumulate_grad_batches or 1))
@@ -113,14 +114,18 @@ class Trainer:
         self.current_epoch, self.global_step, self.should_stop = 0, 0, False
         self.optimizer = None
         self.callback_metrics = {}
+        # [new] optional device-side step between the loader and the model: callable(batch_on_device, training) -> batch
+        # (augment.DevicePipeline: random crop / flips / resize / noise on cached batches)
+        self.batch_transform = batch_transform
 
     def log(self, metrics):
         self.callback_metrics.update(metrics)
         if self.logger is not None:
             self.logger.log_metrics(metrics)
 
-    def _to_device(self, batch):
-        return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    def _to_device(self, batch, training=True):
+        batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        return self.batch_transform(batch, training) if self.batch_transform is not None else batch
 
     def fit(self, model, train_loader, valid_loader=None):
         model.trainer = self
@@ -149,7 +154,7 @@ class Trainer:
                     for i, batch in enumerate(valid_loader):
                         if self.limit_val_batches is not None and i >= self.limit_val_batches:
                             break
-                        model.validation_step(self._to_device(batch), i)
+                        model.validation_step(self._to_device(batch, training=False), i)
                 model.on_validation_epoch_end()
                 for cb in self.callbacks:
                     cb.on_validation_end(self, model, self.callback_metrics)

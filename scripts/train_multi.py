@@ -19,6 +19,8 @@ sys.path.append(str(Path(__file__).resolve().parent.parent))
 from multimodal_plankton_recognition_amd.data import (ImageTransformTest, ImageTransformTrain, MultiSet,  # noqa: E402
                                                       PairAugmentation, ProfileTransformTest,
                                                       ProfileTransformTrain, SyntheticMultiSet, make_multi_collate)
+from multimodal_plankton_recognition_amd.data import CachedMultiSet, cached_collate  # noqa: E402
+from multimodal_plankton_recognition_amd.augment import DevicePipeline  # noqa: E402
 from multimodal_plankton_recognition_amd.model import MultiModel  # noqa: E402
 from multimodal_plankton_recognition_amd.trainer import EarlyStopping, ModelCheckpoint, TensorBoardLogger, Trainer  # noqa: E402
 
@@ -29,6 +31,8 @@ parser.add_argument("--synthetic", type=int, default=0, help="[new] use N synthe
 parser.add_argument("--max-epochs", type=int, default=None, help="[new] override trainer_args.max_epochs")
 parser.add_argument("--limit-batches", type=int, default=None, help="[new] cap batches per epoch (smoke runs)")
 parser.add_argument("--logdir", default="../logs/", help="[new] where runs are written (reference: ../logs/)")
+parser.add_argument("--gpu-augment", action="store_true",
+                    help="[new] cache the deterministic transforms per sample and run crop / flips / resize / noise on the GPU")
 args = parser.parse_args()
 
 card = Path(args.modelcard)
@@ -43,6 +47,10 @@ if args.synthetic:
     data_path = Path('synthetic/data')
     train_set = SyntheticMultiSet(args.synthetic, target_size, seed=1234)
     test_set = SyntheticMultiSet(max(bs, args.synthetic // 4), target_size, seed=4321)
+elif args.gpu_augment:
+    data_path = Path(f'{args.dataset}')
+    train_set = CachedMultiSet(data_path / 'train.csv', target_size, train=True)
+    test_set = CachedMultiSet(data_path / 'test.csv', target_size, train=False)
 else:
     data_path = Path(f'{args.dataset}')
     train_set = MultiSet(annotation_path=data_path / 'train.csv', image_transforms=ImageTransformTrain(target_size),
@@ -58,6 +66,10 @@ model = MultiModel(
     optim_args=card_dict['optim_args'],
 )
 multi_collate = make_multi_collate(model, card_dict['buckets'])
+batch_transform = None
+if args.gpu_augment and not args.synthetic:
+    multi_collate = cached_collate
+    batch_transform = DevicePipeline(model, target_size, card_dict['buckets'])
 
 train_loader = DataLoader(dataset=train_set, batch_size=bs, shuffle=True, num_workers=card_dict['num_workers'],
                           drop_last=True, collate_fn=multi_collate)
@@ -75,7 +87,8 @@ if args.max_epochs is not None:
     trainer_args['max_epochs'] = args.max_epochs
     trainer_args['min_epochs'] = min(trainer_args.get('min_epochs') or 0, args.max_epochs)
 trainer = Trainer(log_every_n_steps=len(train_loader), logger=logger, callbacks=[checkpoint, stopper],
-                  limit_train_batches=args.limit_batches, limit_val_batches=args.limit_batches, **trainer_args)
+                  limit_train_batches=args.limit_batches, limit_val_batches=args.limit_batches,
+                  batch_transform=batch_transform, **trainer_args)
 
 print(f'Training from model card {args.modelcard}')
 trainer.fit(model, train_loader, valid_loader)
