@@ -312,7 +312,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ ymask, const bf16_t* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ partials, long long nvec, int C) {
+    const float* __restrict__ shift, float* __restrict__ partials, long long nvec, int C, int nslices) {
   const int cg = C >> 3;
   __shared__ float red[256][17];
   const int nthr = blockDim.x;   // a multiple of cg (host guarantees), so the channel group is thread-invariant
@@ -345,7 +345,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const int gg = i >> 4, e = i & 15;
     float a = 0.f;
     for (int t = gg; t < nthr; t += cg) a += red[t][e];
-    partials[((size_t)blockIdx.x * 2 + (e >> 3)) * C + gg * 8 + (e & 7)] = a;
+    // nslices > 0: the workgroups add into a few zeroed slice rows (one fp32 atomic per workgroup and sum) -- the
+    // consumer then finalizes from them directly and the pre-reduction launch between the two passes disappears
+    if (nslices > 0) atomicAdd(&partials[((size_t)(blockIdx.x % nslices) * 2 + (e >> 3)) * C + gg * 8 + (e & 7)], a);
+    else partials[((size_t)blockIdx.x * 2 + (e >> 3)) * C + gg * 8 + (e & 7)] = a;
   }
 }
 
@@ -556,7 +559,27 @@ int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float*
   const long long nvec = rows * C / 8;
   const int block = cg_block(C / 8), grid = ew_grid(nvec, block);
   hipStream_t st = (hipStream_t)stream;
-#define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, partials, nvec, C
+#define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, partials, nvec, C, 0
+  if (mask_mode == MASK_NONE) bn_bwd_reduce_kernel<MASK_NONE><<<grid, block, 0, st>>>(ARGS);
+  else if (mask_mode == MASK_Y) bn_bwd_reduce_kernel<MASK_Y><<<grid, block, 0, st>>>(ARGS);
+  else if (mask_mode == MASK_SILU) bn_bwd_reduce_kernel<MASK_SILU><<<grid, block, 0, st>>>(ARGS);
+  else bn_bwd_reduce_kernel<MASK_RECOMPUTE><<<grid, block, 0, st>>>(ARGS);
+#undef ARGS
+  MPR_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+  return MPR_OK;
+}
+
+// the same pass with the sums added into `nslices` rows of slices[nslices][2][C] (zeroed here) instead of one row per workgroup
+int mpr_bn_bwd_reduce_slices(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                             const float* scale, const float* shift, int mask_mode, float* slices, int nslices,
+                             long long rows, int C, void* stream) {
+  MPR_REQUIRE(C % 8 == 0 && C / 8 <= 256 && nslices > 0 && slices, "mpr_bn_bwd_reduce_slices: bad arguments (C=%d)", C);
+  MPR_REQUIRE(mask_mode != MASK_Y || y, "mpr_bn_bwd_reduce_slices: mask_mode 1 needs y");
+  const long long nvec = rows * C / 8;
+  const int block = cg_block(C / 8), grid = ew_grid(nvec, block);
+  hipStream_t st = (hipStream_t)stream;
+  MPR_HIP(hipMemsetAsync(slices, 0, sizeof(float) * 2 * (size_t)nslices * C, st));
+#define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, slices, nvec, C, nslices
   if (mask_mode == MASK_NONE) bn_bwd_reduce_kernel<MASK_NONE><<<grid, block, 0, st>>>(ARGS);
   else if (mask_mode == MASK_Y) bn_bwd_reduce_kernel<MASK_Y><<<grid, block, 0, st>>>(ARGS);
   else if (mask_mode == MASK_SILU) bn_bwd_reduce_kernel<MASK_SILU><<<grid, block, 0, st>>>(ARGS);

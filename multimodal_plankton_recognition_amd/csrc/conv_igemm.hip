@@ -24,6 +24,7 @@ struct ConvGemmParams {
   bf16_t* dst;         // [M][Nout]
   const bf16_t* add;   // optional [M][Nout]
   float* stats;        // optional [gridM][2][Nout]
+  int stat_slices;     // > 0: the tiles ADD their sums into stats[tile % stat_slices] (zeroed by the host) instead of a row each
   int sH, sW, sC;
   unsigned src_bytes, wpk_bytes;   // extents for the buffer descriptors of the LDS-DMA kernel
   unsigned rowpat;                 // sum_r 1 << (r*S): one bit per filter row (tap masks of the LDS-DMA kernel)
@@ -227,7 +228,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGemmParams p)
       const float v = red[(0 * CPR + c) * 16 + e] + red[(1 * CPR + c) * 16 + e] +
                       red[(2 * CPR + c) * 16 + e] + red[(3 * CPR + c) * 16 + e];
       const int n = n0 + c * 8 + (e & 7);
-      if (n < p.Nout) p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
+      if (n < p.Nout) {
+        if (p.stat_slices > 0) atomicAdd(&p.stats[((size_t)(mt % p.stat_slices) * 2 + (e >> 3)) * p.Nout + n], v);
+        else p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
+      }
     }
   }
 }
@@ -567,7 +571,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += red[(w * CPR + c) * 16 + e];
       const int n = n0 + c * 8 + (e & 7);
-      if (n < p.Nout) p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
+      if (n < p.Nout) {
+        if (p.stat_slices > 0) atomicAdd(&p.stats[((size_t)(mt % p.stat_slices) * 2 + (e >> 3)) * p.Nout + n], v);
+        else p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
+      }
     }
   }
   MPR_STAMP(3);
@@ -727,6 +734,17 @@ int mpr_win_stat_rows(int B, int H, int W, int Nout);
 int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, const void* add, float* stats, int B, int H,
                    int W, int srcC, int Nout, hipStream_t st);
 
+// BatchNorm partial sums of the forward convolutions: n > 0 = every tile adds (fp32 atomics) into one of n slice rows that
+// the launcher zeroes -- the consumer finalizes from the n rows directly and the pre-reduction launch between a convolution and
+// its BatchNorm disappears; 0 = one row per tile (bitwise reproducible sums).  Returns the previous setting.
+static int g_stat_slices = 8;
+int mpr_conv_stat_slices() { return g_stat_slices; }
+extern "C" int mpr_conv_set_stat_slices(int n) {
+  const int old = g_stat_slices;
+  g_stat_slices = n < 0 ? 0 : n;
+  return old;
+}
+
 static int g_dma_min_rows = 16384;
 extern "C" int mpr_conv_set_dma_min_rows(int rows) {   // tuning / test knob; returns the previous value
   const int old = g_dma_min_rows;
@@ -810,6 +828,8 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   p.ntn = ceil_div(p.Nout, BN);
   const int gm = ceil_div(p.M, BM);
   dim3 grid(gm * p.ntn);
+  p.stat_slices = (p.stats && !dgrad) ? g_stat_slices : 0;
+  if (p.stat_slices > 0) MPR_HIP(hipMemsetAsync(p.stats, 0, sizeof(float) * 2 * (size_t)p.stat_slices * p.Nout, st));
   // profiler kinds: 0/1 = LDS-DMA kernel fwd/dgrad (the dominant kernel), 3/4 = register-staged kernel fwd/dgrad
   // timing-only experiment (MI355X guide, traffic pricing): a zero-record descriptor drops every load through it
   p.dbg = g_debug_drop;
@@ -881,8 +901,9 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   return MPR_OK;
 }
 
-// Number of row tiles (= rows of the BatchNorm partial-sum buffer) mpr_conv_fwd will use.
+// Rows of the BatchNorm partial-sum buffer mpr_conv_fwd will write (slice rows, or one per row tile).
 int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S, int sh, int sw, int ph, int pw) {
+  if (g_stat_slices > 0) return g_stat_slices;
   if (mpr_win_eligible((long long)B * P * Q, P, Q, C, K, R, S, sh, sw, ph, pw, g_dma_min_rows))   // (stride 1: H == P)
     return mpr_win_stat_rows(B, P, Q, K);
   int mode, BM, BN;

@@ -27,6 +27,7 @@ struct WinParams {
   bf16_t* dst;         // [B,H,W,Nout]
   const bf16_t* add;   // optional residual [B,H,W,Nout]
   float* stats;        // optional [tiles_m][2][Nout]
+  int stat_slices;     // > 0: workgroups ADD into stats[index % stat_slices] (zeroed by the host), see mpr_conv_set_stat_slices
   int H, W, C, Nout;
   int Wp, img, halo, Gtot, wrows;   // W+1, (H+1)*(W+1), W+2, B*img, 256 + 2*halo
   int ntn, Kgpad, ncb;
@@ -371,7 +372,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams 
 #pragma unroll 8
       for (int q = 0; q < RPP; ++q) v += red[(q * CPR + c) * 17 + e];
       const int n = n0 + c * 8 + (e & 7);
-      if (n < p.Nout) p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
+      if (n < p.Nout) {
+        if (p.stat_slices > 0) atomicAdd(&p.stats[((size_t)(mt % p.stat_slices) * 2 + (e >> 3)) * p.Nout + n], v);
+        else p.stats[((size_t)mt * 2 + (e >> 3)) * p.Nout + n] = v;
+      }
     }
   }
   if (p.probe && tid == 0) {
@@ -609,7 +613,10 @@ __global__ __launch_bounds__(256) void conv_win_persist_kernel(const WinParams p
       float v = 0.f;
       for (int q = 0; q < 32; ++q) v += red[(q * 8 + c) * 17 + e];
       const int n = c * 8 + (e & 7);
-      if (n < p.Nout) p.stats[((size_t)blockIdx.x * 2 + (e >> 3)) * p.Nout + n] = v;
+      if (n < p.Nout) {
+        if (p.stat_slices > 0) atomicAdd(&p.stats[((size_t)(blockIdx.x % p.stat_slices) * 2 + (e >> 3)) * p.Nout + n], v);
+        else p.stats[((size_t)blockIdx.x * 2 + (e >> 3)) * p.Nout + n] = v;
+      }
     }
   }
 #endif   // __HIP_DEVICE_COMPILE__
@@ -649,7 +656,9 @@ static inline bool win_persistent(bool dgrad, int Nout, const void* add) {
 }
 
 // rows of the BatchNorm partial-sum buffer the forward launch will write
+int mpr_conv_stat_slices();
 int mpr_win_stat_rows(int B, int H, int W, int Nout) {
+  if (mpr_conv_stat_slices() > 0) return mpr_conv_stat_slices();
   const int tiles = ceil_div(B * (H + 1) * (W + 1), 256);
   return win_persistent(false, Nout, nullptr) ? (tiles < 512 ? tiles : 512) : tiles;
 }
@@ -660,6 +669,8 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
   WinParams p;
   p.src = (const bf16_t*)src; p.wpk = (const bf16_t*)wpk; p.dst = (bf16_t*)dst; p.add = (const bf16_t*)add;
   p.stats = stats;
+  p.stat_slices = (stats && !dgrad) ? mpr_conv_stat_slices() : 0;
+  if (p.stat_slices > 0) MPR_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)p.stat_slices * Nout, st));
   p.H = H; p.W = W; p.C = srcC; p.Nout = Nout;
   p.Wp = W + 1; p.img = (H + 1) * (W + 1); p.halo = W + 2; p.Gtot = B * p.img; p.wrows = 256 + 2 * p.halo;
   p.Kgpad = 9 * srcC; p.ncb = srcC / 64;

@@ -428,6 +428,7 @@ FIN_SLICES = 8
 # pre-reduction launch costs more than every apply workgroup summing <= 16 KB itself (the profile branch's 1-D layers:
 # 14..112 partial rows of 256..32 channels -- ~45 fewer launches per step on that latency-bound stream)
 FIN_DIRECT_FLOATS = int(os.environ.get('MPR_FIN_DIRECT_FLOATS', '4096'))
+BWD_ATOMIC_SLICES = os.environ.get('MPR_BWD_ATOMIC_SLICES', '1') != '0'
 
 
 def _consumer_slices(parts):
@@ -520,12 +521,20 @@ def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False, beta=None):
     C = x.shape[-1]
     rows = x.numel() // C
     dev = x.device
-    parts = torch.empty(N.query('mpr_bn_reduce_rows', rows, C), 2, C, dtype=F32, device=dev)
-    N.call('mpr_bn_bwd_reduce', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, rows, C)
+    nparts = N.query('mpr_bn_reduce_rows', rows, C)
+    direct = FIN_IN_CONSUMER and C <= 512
+    if direct and BWD_ATOMIC_SLICES and nparts * C > FIN_DIRECT_FLOATS:
+        # long partial list: the reduce pass adds into FIN_SLICES rows itself (fp32 atomics), no pre-reduction launch
+        parts = torch.empty(FIN_SLICES, 2, C, dtype=F32, device=dev)
+        N.call('mpr_bn_bwd_reduce_slices', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, FIN_SLICES,
+               rows, C)
+    else:
+        parts = torch.empty(nparts, 2, C, dtype=F32, device=dev)
+        N.call('mpr_bn_bwd_reduce', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, rows, C)
     dgamma, dbeta, acc, ret = _bn_grad_targets(gamma, beta, C, dev)
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
-    if FIN_IN_CONSUMER and C <= 512:
+    if direct:
         slices = _consumer_slices(parts)
         N.call('mpr_bn_bwd_apply_fin', dy, y, x, slices, slices.shape[0], rows, gamma.detach(), st.mean, st.invstd,
                dgamma, dbeta, acc, st.scale, st.shift, mask_mode, dx, dz, rows, C)

@@ -3,7 +3,7 @@
 import sys, time, yaml, torch
 sys.path.insert(0, '.')
 import bench
-from multimodal_plankton_recognition_amd import ops
+from multimodal_plankton_recognition_amd import ops, _native as N
 from multimodal_plankton_recognition_amd.model import MultiModel
 dev = torch.device('cuda', 0)
 card = yaml.safe_load(open(bench.CARD))
@@ -31,8 +31,11 @@ for rep in range(2):
                         ('one stream for both encoders', lambda: setattr(model, 'two_streams', False)),
                         ('weight gradients in-stream', lambda: setattr(ops, 'ASYNC_WGRAD', False)),
                         ('BN partial lists always pre-reduced', lambda: setattr(ops, 'FIN_DIRECT_FLOATS', 0)),
+                        ('BN backward sums via partial rows + pre-reduce', lambda: setattr(ops, 'BWD_ATOMIC_SLICES', False)),
+                        ('conv BN sums one row per tile + pre-reduce', lambda: N.query('mpr_conv_set_stat_slices', 0)),
                         ('both off', lambda: (setattr(model, 'two_streams', False), setattr(ops, 'ASYNC_WGRAD', False)))]:
-        model.two_streams, ops.ASYNC_WGRAD, ops.FIN_DIRECT_FLOATS = True, True, 4096
+        model.two_streams, ops.ASYNC_WGRAD, ops.FIN_DIRECT_FLOATS, ops.BWD_ATOMIC_SLICES = True, True, 4096, True
+        N.query('mpr_conv_set_stat_slices', 8)
         setup()
         print(f'{name:32s} {timed():6.2f} ms/step', flush=True)
 model.two_streams, ops.ASYNC_WGRAD = True, True

@@ -21,6 +21,17 @@ def test_library_exports_every_declared_symbol():
 
 def test_size_queries_match_documented_tiling():
     rows = lambda *a: _native.query('mpr_conv_fwd_stat_rows', *a)
+    # default: every tile adds into one of 8 slice rows (no pre-reduction launch before the BatchNorm that follows)
+    assert rows(512, 56, 56, 64, 64, 3, 3, 1, 1, 1, 1) == 8
+    old_slices = _native.query('mpr_conv_set_stat_slices', 0)      # one row per tile: the documented tilings
+    try:
+        _check_tile_rows(rows)
+    finally:
+        _native.query('mpr_conv_set_stat_slices', old_slices)
+    assert _native.query('mpr_loss_workspace_floats') >= 1024
+
+
+def _check_tile_rows(rows):
     # 3x3 / stride 1 / pad 1: shifted-window kernel, 256 positions of the padded raster (H+1) x (W+1) per tile
     # (N <= 64: the persistent form, one partial row per workgroup, at most 2 workgroups per CU)
     assert rows(512, 56, 56, 64, 64, 3, 3, 1, 1, 1, 1) == min(512, -(-512 * 57 * 57 // 256))
@@ -34,7 +45,6 @@ def test_size_queries_match_documented_tiling():
         _native.query('mpr_conv_set_window', old)
     assert rows(512, 28, 28, 128, 64, 3, 3, 2, 2, 1, 1) == 512 * 28 * 28 // 128          # stride 2: never the window kernel
     assert rows(4, 28, 28, 128, 128, 3, 3, 1, 1, 1, 1) == 4 * 28 * 28 // 128 + 1          # small problem: register-staged kernel
-    assert _native.query('mpr_loss_workspace_floats') >= 1024
 
 
 def test_no_cpu_fallback():
