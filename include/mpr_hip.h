@@ -53,8 +53,10 @@ int mpr_conv_pack_weights_multi(const void* table, int n, void* stream);
 int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S, int sh, int sw, int ph, int pw);
 /* BatchNorm partial sums of mpr_conv_fwd: n > 0 (default 8) = every tile adds its sums (fp32 atomics) into one of n slice
  * rows zeroed by the call, so the consumer finalizes from n rows and no pre-reduction launch sits between a convolution
- * and its BatchNorm; 0 = one row per tile (bitwise reproducible).  Returns the previous setting. */
+ * and its BatchNorm; 0 = one row per tile (bitwise reproducible); n < 0 = query only.  Returns the previous setting. */
 int mpr_conv_set_stat_slices(int n);
+/* one-shot: the slice rows given to the NEXT mpr_conv_fwd are already zero (skip its memset) */
+int mpr_conv_stats_prezeroed(int on);
 /* 3x3 / stride 1 / pad 1 convolutions with source channels % 64 == 0 (forward and data gradient) run on the
  * shifted-window kernel (conv_win.hip: the haloed activation window is loaded once per 64-channel block and all nine
  * taps read it at shifted LDS rows); 0 switches it off (tests / comparisons); returns the previous setting */
@@ -139,11 +141,12 @@ int mpr_bn_apply(const void* x, const float* scale, const float* shift, const vo
 int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                       const float* scale, const float* shift, int mask_mode, float* partials, long long rows, int C,
                       void* stream);
-/* the same reduction with every workgroup adding into one of `nslices` rows of slices[nslices][2][C] (zeroed by the call):
+/* the same reduction with every workgroup adding into one of `nslices` rows of slices[nslices][2][C] (zeroed by the call unless `prezeroed`):
  * the consumer (mpr_bn_bwd_apply_fin) finalizes from them directly, no pre-reduction launch in between */
 int mpr_bn_bwd_reduce_slices(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                              const float* scale, const float* shift, int mask_mode, float* slices, int nslices,
-                             long long rows, int C, void* stream);
+                             int prezeroed /* the rows are already zero: skip the memset */, long long rows, int C,
+                             void* stream);
 int mpr_bn_bwd_finalize(const float* partials, int nparts, long long count, const float* gamma, const float* mean,
                         const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef /* [3][C] */,
                         int C, void* stream);

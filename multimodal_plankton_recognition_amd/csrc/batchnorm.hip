@@ -572,13 +572,13 @@ int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float*
 // the same pass with the sums added into `nslices` rows of slices[nslices][2][C] (zeroed here) instead of one row per workgroup
 int mpr_bn_bwd_reduce_slices(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                              const float* scale, const float* shift, int mask_mode, float* slices, int nslices,
-                             long long rows, int C, void* stream) {
+                             int prezeroed, long long rows, int C, void* stream) {
   MPR_REQUIRE(C % 8 == 0 && C / 8 <= 256 && nslices > 0 && slices, "mpr_bn_bwd_reduce_slices: bad arguments (C=%d)", C);
   MPR_REQUIRE(mask_mode != MASK_Y || y, "mpr_bn_bwd_reduce_slices: mask_mode 1 needs y");
   const long long nvec = rows * C / 8;
   const int block = cg_block(C / 8), grid = ew_grid(nvec, block);
   hipStream_t st = (hipStream_t)stream;
-  MPR_HIP(hipMemsetAsync(slices, 0, sizeof(float) * 2 * (size_t)nslices * C, st));
+  if (!prezeroed) MPR_HIP(hipMemsetAsync(slices, 0, sizeof(float) * 2 * (size_t)nslices * C, st));
 #define ARGS (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, slices, nvec, C, nslices
   if (mask_mode == MASK_NONE) bn_bwd_reduce_kernel<MASK_NONE><<<grid, block, 0, st>>>(ARGS);
   else if (mask_mode == MASK_Y) bn_bwd_reduce_kernel<MASK_Y><<<grid, block, 0, st>>>(ARGS);

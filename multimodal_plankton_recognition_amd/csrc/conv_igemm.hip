@@ -739,9 +739,21 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
 // its BatchNorm disappears; 0 = one row per tile (bitwise reproducible sums).  Returns the previous setting.
 static int g_stat_slices = 8;
 int mpr_conv_stat_slices() { return g_stat_slices; }
+// one-shot promise of the caller that the slice rows handed to the NEXT mpr_conv_fwd are already zero (a per-step arena
+// zeroed in one go): the launcher then skips its own memset -- 40 fill launches of ~5 us per C3 step otherwise
+static int g_stats_prezeroed = 0;
+extern "C" int mpr_conv_stats_prezeroed(int on) {
+  g_stats_prezeroed = on;
+  return 0;
+}
+bool mpr_conv_take_prezeroed() {
+  const bool v = g_stats_prezeroed != 0;
+  g_stats_prezeroed = 0;
+  return v;
+}
 extern "C" int mpr_conv_set_stat_slices(int n) {
   const int old = g_stat_slices;
-  g_stat_slices = n < 0 ? 0 : n;
+  if (n >= 0) g_stat_slices = n;          // (n < 0: query only)
   return old;
 }
 
@@ -829,7 +841,11 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   const int gm = ceil_div(p.M, BM);
   dim3 grid(gm * p.ntn);
   p.stat_slices = (p.stats && !dgrad) ? g_stat_slices : 0;
-  if (p.stat_slices > 0) MPR_HIP(hipMemsetAsync(p.stats, 0, sizeof(float) * 2 * (size_t)p.stat_slices * p.Nout, st));
+  {
+    const bool prezeroed = mpr_conv_take_prezeroed();
+    if (p.stat_slices > 0 && !prezeroed)
+      MPR_HIP(hipMemsetAsync(p.stats, 0, sizeof(float) * 2 * (size_t)p.stat_slices * p.Nout, st));
+  }
   // profiler kinds: 0/1 = LDS-DMA kernel fwd/dgrad (the dominant kernel), 3/4 = register-staged kernel fwd/dgrad
   // timing-only experiment (MI355X guide, traffic pricing): a zero-record descriptor drops every load through it
   p.dbg = g_debug_drop;

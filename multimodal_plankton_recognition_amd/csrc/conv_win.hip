@@ -657,6 +657,7 @@ static inline bool win_persistent(bool dgrad, int Nout, const void* add) {
 
 // rows of the BatchNorm partial-sum buffer the forward launch will write
 int mpr_conv_stat_slices();
+bool mpr_conv_take_prezeroed();
 int mpr_win_stat_rows(int B, int H, int W, int Nout) {
   if (mpr_conv_stat_slices() > 0) return mpr_conv_stat_slices();
   const int tiles = ceil_div(B * (H + 1) * (W + 1), 256);
@@ -670,7 +671,11 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
   p.src = (const bf16_t*)src; p.wpk = (const bf16_t*)wpk; p.dst = (bf16_t*)dst; p.add = (const bf16_t*)add;
   p.stats = stats;
   p.stat_slices = (stats && !dgrad) ? mpr_conv_stat_slices() : 0;
-  if (p.stat_slices > 0) MPR_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)p.stat_slices * Nout, st));
+  {
+    const bool prezeroed = mpr_conv_take_prezeroed();
+    if (p.stat_slices > 0 && !prezeroed)
+      MPR_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)p.stat_slices * Nout, st));
+  }
   p.H = H; p.W = W; p.C = srcC; p.Nout = Nout;
   p.Wp = W + 1; p.img = (H + 1) * (W + 1); p.halo = W + 2; p.Gtot = B * p.img; p.wrows = 256 + 2 * p.halo;
   p.Kgpad = 9 * srcC; p.ncb = srcC / 64;

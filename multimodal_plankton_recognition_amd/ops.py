@@ -208,7 +208,13 @@ def conv_fwd(x, wf, g, want_stats):
     stats = None
     if want_stats:
         rows = N.query('mpr_conv_fwd_stat_rows', B, P, Q, g.K, C, *g.tail)
-        stats = torch.empty(rows, 2, g.K, dtype=F32, device=x.device)
+        zeroed = False
+        if rows == FIN_SLICES and N.query('mpr_conv_set_stat_slices', -1) == FIN_SLICES:     # slice rows (atomics)
+            stats, zeroed = _slice_rows(g.K, x.device)
+        else:
+            stats = torch.empty(rows, 2, g.K, dtype=F32, device=x.device)
+        if zeroed:
+            N.query('mpr_conv_stats_prezeroed', 1)
     N.call('mpr_conv_fwd', x, wf, y, stats, B, H, W, C, g.K, *g.tail)
     return y, stats
 
@@ -429,6 +435,33 @@ FIN_SLICES = 8
 # 14..112 partial rows of 256..32 channels -- ~45 fewer launches per step on that latency-bound stream)
 FIN_DIRECT_FLOATS = int(os.environ.get('MPR_FIN_DIRECT_FLOATS', '4096'))
 BWD_ATOMIC_SLICES = os.environ.get('MPR_BWD_ATOMIC_SLICES', '1') != '0'
+# The slice rows come from a per-device arena that is zeroed ONCE per step (FusedSGD.zero_grad -> reset_slice_arena): a
+# memset per BatchNorm is a ~5 us fill launch, 77 of them per C3 step.  When the arena runs out (no optimizer resetting it,
+# or more BatchNorm calls per step than slots) the launcher zeroes a fresh buffer itself.
+SLICE_ARENA = os.environ.get('MPR_SLICE_ARENA', '1') != '0'
+_SLICE_SLOTS, _SLICE_FLOATS = 512, FIN_SLICES * 2 * 512
+_slice_arena = {}          # device -> [tensor [slots][floats], next free slot]
+
+
+def _slice_rows(C, dev):
+    """-> (zero-able tensor [FIN_SLICES, 2, C], already zero?)."""
+    if SLICE_ARENA and FIN_SLICES * 2 * C <= _SLICE_FLOATS:
+        a = _slice_arena.get(dev)
+        if a is None:
+            a = _slice_arena[dev] = [torch.zeros(_SLICE_SLOTS, _SLICE_FLOATS, dtype=F32, device=dev), 0]
+        if a[1] < _SLICE_SLOTS:
+            t = a[0][a[1]][:FIN_SLICES * 2 * C].view(FIN_SLICES, 2, C)
+            a[1] += 1
+            return t, True
+    return torch.empty(FIN_SLICES, 2, C, dtype=F32, device=dev), False
+
+
+def reset_slice_arena():
+    """Start of an optimisation step (every stream has been joined): zero the used part of each arena in one go."""
+    for a in _slice_arena.values():
+        if a[1]:
+            a[0][:a[1]].zero_()
+            a[1] = 0
 
 
 def _consumer_slices(parts):
@@ -525,9 +558,9 @@ def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False, beta=None):
     direct = FIN_IN_CONSUMER and C <= 512
     if direct and BWD_ATOMIC_SLICES and nparts * C > FIN_DIRECT_FLOATS:
         # long partial list: the reduce pass adds into FIN_SLICES rows itself (fp32 atomics), no pre-reduction launch
-        parts = torch.empty(FIN_SLICES, 2, C, dtype=F32, device=dev)
+        parts, zeroed = _slice_rows(C, dev)
         N.call('mpr_bn_bwd_reduce_slices', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, FIN_SLICES,
-               rows, C)
+               int(zeroed), rows, C)
     else:
         parts = torch.empty(nparts, 2, C, dtype=F32, device=dev)
         N.call('mpr_bn_bwd_reduce', dy, y, x, st.mean, st.invstd, st.scale, st.shift, mask_mode, parts, rows, C)
@@ -747,6 +780,7 @@ class FusedSGD:
             return
         self._install()
         self.flat_grad.zero_()
+        reset_slice_arena()
         for p, v in zip(self.params, self._views):
             if p.grad is not v:
                 p.grad = v

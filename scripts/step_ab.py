@@ -33,8 +33,10 @@ for rep in range(2):
                         ('BN partial lists always pre-reduced', lambda: setattr(ops, 'FIN_DIRECT_FLOATS', 0)),
                         ('BN backward sums via partial rows + pre-reduce', lambda: setattr(ops, 'BWD_ATOMIC_SLICES', False)),
                         ('conv BN sums one row per tile + pre-reduce', lambda: N.query('mpr_conv_set_stat_slices', 0)),
+                        ('slice rows zeroed per call (no arena)', lambda: setattr(ops, 'SLICE_ARENA', False)),
                         ('both off', lambda: (setattr(model, 'two_streams', False), setattr(ops, 'ASYNC_WGRAD', False)))]:
         model.two_streams, ops.ASYNC_WGRAD, ops.FIN_DIRECT_FLOATS, ops.BWD_ATOMIC_SLICES = True, True, 4096, True
+        ops.SLICE_ARENA = True
         N.query('mpr_conv_set_stat_slices', 8)
         setup()
         print(f'{name:32s} {timed():6.2f} ms/step', flush=True)
