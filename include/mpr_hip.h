@@ -124,6 +124,34 @@ int mpr_stem_fwd(const float* x, const float* w_oihw, void* y, float* stats /* m
 int mpr_stem_wgrad(const float* x, const void* dy, float* dw_oihw, int accumulate, int B, int H, int W, int Cin,
                    int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
 
+/* ---- ResNet stem, fused and recomputed (stem_fused.hip): conv 7x7/2 (1 -> 64) + BatchNorm + ReLU + MaxPool 3x3/2 of
+ * timm's ResNet (conv1 / bn1 / act1 / maxpool behind src/image_encoder.py:16,24) without ever storing the
+ * full-resolution conv output (822 MB at batch 512): the forward recomputes the cheap convolution in both of its passes,
+ * the backward needs no convolution at all (conv linearity: it accumulates dz^T * patches and the patch Gram matrix). */
+int mpr_stemf_supported(int H, int W, int K);      /* 1 iff this geometry is served (K == 64, H % 4 == 0, W % 32 == 0) */
+/* x fp32 [B,H,W] (one channel) -> xb bf16 [B][H+6][W+8], zero padded; w fp32 [64][1][7][7] -> wp bf16 [64][64] */
+int mpr_stemf_prep(const float* x, const float* w, void* xb, void* wp, int B, int H, int W, void* stream);
+/* pass A: per-channel sum / sum of squares of the bf16-rounded conv output, ADDED into stats[nslices][2][64] (zeroed here
+ * unless `prezeroed`) */
+int mpr_stemf_stats(const void* xb, const void* wp, float* stats, int nslices, int prezeroed, int B, int H, int W,
+                    void* stream);
+/* pass B: pooled [B,H/4,W/4,64] bf16 = maxpool(relu(bn(conv))).  slices != NULL (train): the statistics are finalized
+ * here -- scale, shift, mean, invstd are OUTPUTS, the running statistics are updated; slices == NULL (eval): scale and
+ * shift are inputs.  idx (may be NULL): 1-byte arg-max code kh*3+kw per pooled element, first maximum in torch's scan
+ * order, 15 where the pooled activation is 0 (the winner's ReLU derivative is 0: no gradient) -- all mpr_stemf_bwd needs. */
+int mpr_stemf_pool(const void* xb, const void* wp, const float* slices, int nsl, long long count, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                   float* shift, float* mean, float* invstd, void* pooled, void* idx, int B, int H, int W, void* stream);
+int mpr_stemf_bwd_parts(int B, int H, int W);      /* partial blocks (7168 floats each) mpr_stemf_bwd writes */
+int mpr_stemf_bwd(const void* xb, const void* dpooled, const void* idx, float* partial, int B, int H, int W,
+                  void* stream);
+/* partial blocks -> dW [64][1][7][7], dgamma, dbeta (accumulated into what is there when the flag is set).
+ * scratch: 7168 doubles.  eval != 0: BatchNorm ran on the running statistics (mean = running_mean, invstd_or_var =
+ * running_var): dx = scale * dz */
+int mpr_stemf_bwd_finalize(const float* partial, int nparts, void* scratch, const void* wp, long long count,
+                           const float* gamma, const float* mean, const float* invstd_or_var, float eps, int eval,
+                           float* dw, int accumulate_dw, float* dgamma, float* dbeta, int accumulate_bn, void* stream);
+
 /* ---- BatchNorm, train and eval (nn.BatchNorm1d/2d defaults: src/profile_encoder.py:126,129,168) */
 int mpr_bn_reduce_rows(long long rows, int C);
 int mpr_bn_stats(const void* x, float* partials, long long rows, int C, void* stream);

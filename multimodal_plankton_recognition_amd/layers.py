@@ -73,6 +73,19 @@ class StemFn(torch.autograd.Function):
     def forward(ctx, x, conv_w, bn_w, bn_b, mod):
         g = mod.geom
         train = mod.training
+        ctx.train = train
+        ctx.fused = ops.stemf_ok(x, g)
+        if ctx.fused:
+            # ResNet stem, 1 channel, 64 filters: fused + recomputed (csrc/stem_fused.hip) -- the full-resolution conv
+            # output is never stored; eval-mode BatchNorm (running statistics) has a backward pass here as well
+            want_bwd = any(ctx.needs_input_grad[1:4])
+            pooled, st, saved = ops.stemf_forward(x, conv_w, mod.bn1, train, want_bwd)
+            if train:
+                mod.bn1.count_batch()
+            if want_bwd:
+                ctx.save_for_backward(*saved, conv_w, bn_w, bn_b)
+                ctx.st, ctx.bn = st, mod.bn1
+            return pooled
         # ResNet stem (1 channel, 7x7/2, pad 3, even image): space-to-depth -> MFMA implicit GEMM
         s2d = (x.dim() == 4 and g.C == 1 and g.R == 7 and g.S == 7 and g.sh == 2 and g.ph == 3
                and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and g.K % 8 == 0)
@@ -87,11 +100,15 @@ class StemFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(x, y, idx, conv_w, bn_w, bn_b)
             ctx.st, ctx.g, ctx.s2d = st, g, s2d
-        ctx.train = train
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
+        if ctx.fused:
+            xb, wp, idx, conv_w, bn_w, bn_b = ctx.saved_tensors
+            dw, dgamma, dbeta = ops.stemf_backward(dpooled.contiguous(), xb, wp, idx, conv_w, bn_w, bn_b, ctx.st,
+                                                   ctx.bn, ctx.train)
+            return None, dw, dgamma, dbeta, None
         if not ctx.train:
             raise RuntimeError('backward through an eval-mode BatchNorm stem is not implemented')
         x, y, idx, conv_w, bn_w, bn_b = ctx.saved_tensors

@@ -398,6 +398,75 @@ def stem_wgrad(x, dy, g, weight):
     return dw
 
 
+# ------------------------------------------------------------------------------------------ fused ResNet stem
+STEM_FUSED = os.environ.get('MPR_STEM_FUSED', '1') != '0'
+STEMF_SLICES = 64
+
+
+def stemf_ok(x, g):
+    """Is (input, stem geometry) served by the fused / recomputed stem of csrc/stem_fused.hip?"""
+    return (STEM_FUSED and x.dim() == 4 and x.shape[3] == 1 and g.C == 1 and g.K == 64
+            and (g.R, g.S, g.sh, g.sw, g.ph, g.pw) == (7, 7, 2, 2, 3, 3)
+            and bool(N.query('mpr_stemf_supported', x.shape[1], x.shape[2], g.K)))
+
+
+def stemf_forward(x, weight, bn, train, want_bwd):
+    """x fp32 [B,H,W,1] -> pooled bf16 [B,H/4,W/4,64] (= maxpool(relu(bn(conv7x7/2(x))))), BNState, saved tensors for
+    stemf_backward (xb, wp, idx).  The full-resolution conv output is never stored."""
+    B, H, W, _ = x.shape
+    dev = x.device
+    xb = torch.empty(B, H + 6, W + 8, dtype=BF16, device=dev)
+    wp = torch.empty(64, 64, dtype=BF16, device=dev)
+    N.call('mpr_stemf_prep', x, weight.detach(), xb, wp, B, H, W)
+    st = BNState()
+    st.pending = None
+    st.scale = torch.empty(64, dtype=F32, device=dev)
+    st.shift = torch.empty(64, dtype=F32, device=dev)
+    pooled = torch.empty(B, H // 4, W // 4, 64, dtype=BF16, device=dev)
+    idx = torch.empty(pooled.shape, dtype=torch.uint8, device=dev) if want_bwd else None
+    count = B * (H // 2) * (W // 2)
+    if train:
+        # 64 slice rows: same-address global atomics serialise, and 64 x 128 floats are nothing for the consumer to sum
+        stats, zeroed = _slice_rows(64, dev, STEMF_SLICES)
+        N.call('mpr_stemf_stats', xb, wp, stats, STEMF_SLICES, int(zeroed), B, H, W)
+        st.mean = torch.empty(64, dtype=F32, device=dev)
+        st.invstd = torch.empty(64, dtype=F32, device=dev)
+        N.call('mpr_stemf_pool', xb, wp, stats, STEMF_SLICES, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+               bn.running_var, float(bn.momentum), float(bn.eps), st.scale, st.shift, st.mean, st.invstd, pooled, idx,
+               B, H, W)
+    else:
+        st.mean = st.invstd = None
+        N.call('mpr_bn_eval_coefs', bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+               float(bn.eps), st.scale, st.shift, 64)
+        N.call('mpr_stemf_pool', xb, wp, None, 0, count, None, None, None, None, 0.0, float(bn.eps), st.scale, st.shift,
+               None, None, pooled, idx, B, H, W)
+    return pooled, st, (xb, wp, idx)
+
+
+def stemf_backward(dpooled, xb, wp, idx, weight, gamma, beta, st, bn, train):
+    """-> (dw, dgamma, dbeta); None where accumulated into the optimizer's gradient memory."""
+    B, H, W = xb.shape[0], xb.shape[1] - 6, xb.shape[2] - 8
+    dev = xb.device
+    parts = N.query('mpr_stemf_bwd_parts', B, H, W)
+    partial = torch.empty(parts, 7168, dtype=F32, device=dev)
+    scratch = torch.empty(7168, dtype=torch.float64, device=dev)
+    N.call('mpr_stemf_bwd', xb, dpooled, idx, partial, B, H, W)
+    dgamma, dbeta, acc_bn, ret = _bn_grad_targets(gamma, beta, 64, dev)
+    tgt = grad_target(weight)
+    if tgt is not None and tgt.is_contiguous():
+        dw, acc_dw = tgt, 1
+    else:
+        dw, acc_dw, tgt = torch.empty(weight.shape, dtype=F32, device=dev), 0, None
+    count = B * (H // 2) * (W // 2)
+    if train:
+        N.call('mpr_stemf_bwd_finalize', partial, parts, scratch, wp, count, gamma.detach(), st.mean, st.invstd, 0.0, 0,
+               dw, acc_dw, dgamma, dbeta, acc_bn)
+    else:
+        N.call('mpr_stemf_bwd_finalize', partial, parts, scratch, wp, count, gamma.detach(), bn.running_mean,
+               bn.running_var, float(bn.eps), 1, dw, acc_dw, dgamma, dbeta, acc_bn)
+    return (None if tgt is not None else dw), (dgamma if ret else None), (dbeta if ret else None)
+
+
 # ------------------------------------------------------------------------------------------ batch norm
 _ticket_pool = {}
 # Measured WORSE and therefore off: the last-workgroup pattern needs agent-scope release/acquire fences, and a release
@@ -443,17 +512,17 @@ _SLICE_SLOTS, _SLICE_FLOATS = 512, FIN_SLICES * 2 * 512
 _slice_arena = {}          # device -> [tensor [slots][floats], next free slot]
 
 
-def _slice_rows(C, dev):
-    """-> (zero-able tensor [FIN_SLICES, 2, C], already zero?)."""
-    if SLICE_ARENA and FIN_SLICES * 2 * C <= _SLICE_FLOATS:
+def _slice_rows(C, dev, nslices=FIN_SLICES):
+    """-> (zero-able tensor [nslices, 2, C], already zero?)."""
+    if SLICE_ARENA and nslices * 2 * C <= _SLICE_FLOATS:
         a = _slice_arena.get(dev)
         if a is None:
             a = _slice_arena[dev] = [torch.zeros(_SLICE_SLOTS, _SLICE_FLOATS, dtype=F32, device=dev), 0]
         if a[1] < _SLICE_SLOTS:
-            t = a[0][a[1]][:FIN_SLICES * 2 * C].view(FIN_SLICES, 2, C)
+            t = a[0][a[1]][:nslices * 2 * C].view(nslices, 2, C)
             a[1] += 1
             return t, True
-    return torch.empty(FIN_SLICES, 2, C, dtype=F32, device=dev), False
+    return torch.empty(nslices, 2, C, dtype=F32, device=dev), False
 
 
 def reset_slice_arena():
