@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, 'libmpr_hip.so')
+LIB_PATH = os.environ.get('MPR_HIP_LIB') or os.path.join(_HERE, 'libmpr_hip.so')     # (override: A/B of two builds)
 HEADER_PATH = os.path.join(_ROOT, 'include', 'mpr_hip.h')
 
 

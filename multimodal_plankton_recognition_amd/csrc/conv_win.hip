@@ -51,7 +51,7 @@ __device__ __forceinline__ void wait_vmcnt_win() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int STAGES, bool DGRAD>
+template <int WM, int WN, int TM, int TN, int STAGES, bool DGRAD, bool ADD = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WM * WN, T = 64 * NW;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams 
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  if (!p.add) {
+  if (!ADD) {
     // No residual: the tile is rounded to bf16 IN REGISTERS and staged as bf16 (half the LDS bytes), every wave writing
     // its own rows at once -- one pass of 256 rows at BN = 64, two of 128 rows at BN = 128 (LDS capacity) -- and the
     // read side hands finished 16-B channel groups to the global store.  (The slab path below serialises the waves and
@@ -300,57 +300,66 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams 
       }
       pr_er += PROBE_NOW() - e1;
     }
-  } else
+  } else {
+    // Fused residual (the skip-connection gradient of a data gradient) must see the UNROUNDED accumulator: the tile is
+    // staged as fp32, every wave whose rows are in the pass writing at once -- the whole 256 x 64 tile in ONE pass (69 KB,
+    // inside the window + ring allocation), a 256 x 128 tile in four 64-row passes -- and the read side adds the residual
+    // in coalesced 16-B channel groups.  (Until round 2 this walked 64-row slabs with one writing wave each: four barrier
+    // pairs on the 64-channel tile, 289 vs 194 us without the residual on the 64 -> 64 @ 56x56 data gradient.)
+    constexpr int EPA = BN == 64 ? 1 : 4;
+    constexpr int RPA = BM / EPA;
+    static_assert(RPA % RPP == 0 && RPA % 32 == 0, "a pass is whole row passes of whole m-tiles");
 #pragma unroll
-  for (int slab = 0; slab < BM / 64; ++slab) {
-    win_lds_barrier();
-    if (wm == slab / (TM / 2)) {
+    for (int ep = 0; ep < EPA; ++ep) {
+      win_lds_barrier();
 #pragma unroll
-      for (int il = 0; il < 2; ++il) {
-        const int i = (slab % (TM / 2)) * 2 + il;
+      for (int i = 0; i < TM; ++i) {
+        const int grow = wm * (TM * 32) + i * 32;          // this 32-row m-tile inside the 256-row tile (wave-uniform)
+        if (grow / RPA == ep) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+          for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int row = il * 32 + frow;
-            const int col = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
-            float4 v = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
-            *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
-          }
+            for (int g = 0; g < 4; ++g) {
+              const int row = grow - ep * RPA + frow;
+              const int col = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
+              float4 v = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+              *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
+            }
+        }
       }
-    }
-    win_lds_barrier();
-#pragma unroll 2
-    for (int r = rr; r < 64; r += RPP) {
-      const int G = G0 + slab * 64 + r;
-      bool row_ok = G < p.Gtot;
-      uint32_t pix = 0;
-      if (row_ok) {
-        const uint32_t b = fdiv(G, p.div_img);
-        const uint32_t pp = G - b * p.img;
-        const uint32_t hh = fdiv(pp, p.div_wp);
-        const uint32_t ww = pp - hh * p.Wp;
-        row_ok = hh < (uint32_t)p.H && ww < (uint32_t)p.W;
-        pix = (b * p.H + hh) * p.W + ww;
-      }
-      if (row_ok && col_ok) {
-        const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
-        const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
-        float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const size_t o = (size_t)pix * p.Nout + ncol;
-        if (p.add) {
+      win_lds_barrier();
+      constexpr int NRA = RPA / RPP;
+#pragma unroll 4
+      for (int n = 0; n < NRA; ++n) {
+        const int r = rr + n * RPP;
+        const int G = G0 + ep * RPA + r;
+        bool row_ok = G < p.Gtot;
+        uint32_t pix = 0;
+        if (row_ok) {
+          const uint32_t b = fdiv(G, p.div_img);
+          const uint32_t pp = G - b * p.img;
+          const uint32_t hh = fdiv(pp, p.div_wp);
+          const uint32_t ww = pp - hh * p.Wp;
+          row_ok = hh < (uint32_t)p.H && ww < (uint32_t)p.W;
+          pix = (b * p.H + hh) * p.W + ww;
+        }
+        if (row_ok && col_ok) {
+          const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
+          const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
+          float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          const size_t o = (size_t)pix * p.Nout + ncol;
           float g[8];
           unpack8(*reinterpret_cast<const uint4*>(p.add + o), g);
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] += g[e];
-        }
-        const uint4 pk = pack8(f);
-        *reinterpret_cast<uint4*>(p.dst + o) = pk;
-        if (p.stats) {
-          float q[8];
-          unpack8(pk, q);
+          const uint4 pk = pack8(f);
+          *reinterpret_cast<uint4*>(p.dst + o) = pk;
+          if (p.stats) {
+            float q[8];
+            unpack8(pk, q);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+            for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+          }
         }
       }
     }
@@ -726,7 +735,19 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
     const size_t lds = lds_pad + wbytes + (size_t)ST_ * (WN_ * TN_ * 32) * 128;                            \
     conv_win_kernel<WM_, WN_, TM_, TN_, ST_, DG_><<<grid, 64 * WM_ * WN_, lds, st>>>(p);                   \
   } while (0)
-#define MPR_WIN2(WM_, WN_, TM_, TN_, ST_) do { if (dgrad) MPR_WIN(WM_, WN_, TM_, TN_, ST_, true); else MPR_WIN(WM_, WN_, TM_, TN_, ST_, false); } while (0)
+#define MPR_WINA(WM_, WN_, TM_, TN_, ST_)                                                                  \
+  do {                                                                                                     \
+    static bool attr_set = false;                                                                          \
+    if (!attr_set) {                                                                                       \
+      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, true>,               \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      attr_set = true;                                                                                     \
+    }                                                                                                      \
+    const size_t ring_ = lds_pad + wbytes + (size_t)ST_ * (WN_ * TN_ * 32) * 128;                          \
+    const size_t epi_ = (size_t)((WN_ * TN_ * 32) == 64 ? 256 : 64) * ((WN_ * TN_ * 32) * 4 + 16);         \
+    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, true><<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p); \
+  } while (0)
+#define MPR_WIN2(WM_, WN_, TM_, TN_, ST_) do { if (dgrad && add) MPR_WINA(WM_, WN_, TM_, TN_, ST_); else if (dgrad) MPR_WIN(WM_, WN_, TM_, TN_, ST_, true); else MPR_WIN(WM_, WN_, TM_, TN_, ST_, false); } while (0)
   if (BN == 64) {
     switch (g_win_variant_) {
       case 1: MPR_WIN2(4, 1, 2, 2, 2); break;
@@ -742,6 +763,7 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
     }
   }
 #undef MPR_WIN2
+#undef MPR_WINA
 #undef MPR_WIN
   MPR_LAUNCH_CHECK("conv_win_kernel");
   return MPR_OK;
