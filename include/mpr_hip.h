@@ -111,6 +111,18 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace /* K*R*S*C fl
                    int accumulate, int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph,
                    int pw, void* stream);
 
+/* Data gradient of a 3x3 / stride 1 / pad 1 convolution whose INPUT was the output of BatchNorm (+ ReLU) -- timm
+ * BasicBlock / _BasicBlock (src/profile_encoder.py:132-148: conv -> BN -> ReLU -> conv -> BN -> add -> ReLU): the epilogue
+ * applies the ReLU mask and accumulates that BatchNorm's backward sums, dz = mask * (conv_transpose(dy, w) (+ add)),
+ * slices[nslices][2][C] += (sum dz, sum dz * (bn_x - mean) * invstd) -- the separate reduction pass over (dy, y, x) of
+ * mpr_bn_bwd_reduce disappears (then: mpr_bn_bwd_apply_fin with mask_mode 0 on dz).
+ * mask_mode 1: mask = mask_y > 0 (the block output);  2: mask = bf16(bn_x * scale + shift) > 0 (recomputed). */
+int mpr_conv_dgrad_bn_supported(int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw);
+int mpr_conv_dgrad_bn(const void* dy, const void* w_dgrad, void* dz, const void* add /* may be NULL */, int mask_mode,
+                      const void* mask_y, const void* bn_x, const float* mean, const float* invstd, const float* scale,
+                      const float* shift, float* slices, int nslices, int prezeroed, int B, int H, int W, int C, int K,
+                      int R, int S, int sh, int sw, int ph, int pw, void* stream);
+
 /* ---- stem convolutions (few input channels, fp32 input, direct) -----------------------------
  * timm ResNet conv1 (1->64, 7x7/2) and ProfileCNN.conv1 (src/profile_encoder.py:167). */
 /* ResNet stem as space-to-depth (7x7/2 on 1 channel == 4x4/1 on the 4 (+4 zero) phase channels, halo

@@ -731,8 +731,15 @@ int mpr_conv_pack_weights_multi(const void* table, int n, void* stream) {
 bool mpr_win_eligible(long long M, int H, int W, int srcC, int Nout, int R, int S, int sh, int sw, int ph, int pw,
                       long long min_rows);
 int mpr_win_stat_rows(int B, int H, int W, int Nout);
+struct WinBnb {   // BatchNorm-backward fusion of a data gradient (conv_win.hip)
+  int mask_mode;
+  const void *mask_y, *bn_x;
+  const float *mean, *invstd, *scale, *shift;
+  float* slices;
+  int nslices, prezeroed;
+};
 int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, const void* add, float* stats, int B, int H,
-                   int W, int srcC, int Nout, hipStream_t st);
+                   int W, int srcC, int Nout, hipStream_t st, const WinBnb* bnb);
 
 // BatchNorm partial sums of the forward convolutions: n > 0 = every tile adds (fp32 atomics) into one of n slice rows that
 // the launcher zeroes -- the consumer finalizes from the n rows directly and the pre-reduction launch between a convolution and
@@ -941,7 +948,7 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
     // 3x3 / stride 1 / pad 1: shifted-window kernel (conv_win.hip)
     void* tok = mpr_prof_begin(0, 2.0 * (double)B * P * Q * K * 9.0 * C, (hipStream_t)stream);
     mpr_prof_bytes(tok, 2.0 * ((double)B * H * W * C + 9.0 * C * K + (double)B * P * Q * K));
-    const int rc = mpr_win_launch(false, x, w_fwd, y, nullptr, stats, B, H, W, C, K, (hipStream_t)stream);
+    const int rc = mpr_win_launch(false, x, w_fwd, y, nullptr, stats, B, H, W, C, K, (hipStream_t)stream, nullptr);
     mpr_prof_end(tok, (hipStream_t)stream);
     return rc;
   }
@@ -969,7 +976,7 @@ int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* ad
   if (mpr_win_eligible((long long)B * H * W, H, W, K, C, R, S, sh, sw, ph, pw, g_dma_min_rows)) {
     void* tok = mpr_prof_begin(1, 2.0 * (double)B * H * W * C * 9.0 * K, (hipStream_t)stream);
     mpr_prof_bytes(tok, 2.0 * ((double)B * P * Q * K + 9.0 * C * K + (double)B * H * W * C * (add ? 2 : 1)));
-    const int rc = mpr_win_launch(true, dy, w_dgrad, dx, add, nullptr, B, H, W, K, C, (hipStream_t)stream);
+    const int rc = mpr_win_launch(true, dy, w_dgrad, dx, add, nullptr, B, H, W, K, C, (hipStream_t)stream, nullptr);
     mpr_prof_end(tok, (hipStream_t)stream);
     return rc;
   }
@@ -983,6 +990,32 @@ int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* ad
   p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
   p.Pm = H; p.Qm = W; p.div_pq = make_fastdiv(H * W); p.div_q = make_fastdiv(W);
   return launch_igemm(true, p, (hipStream_t)stream);
+}
+
+// Is the data gradient with fused BatchNorm-backward reduction (mpr_conv_dgrad_bn) available for this geometry?
+int mpr_conv_dgrad_bn_supported(int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw) {
+  return mpr_win_eligible((long long)B * H * W, H, W, K, C, R, S, sh, sw, ph, pw, g_dma_min_rows) ? 1 : 0;
+}
+
+// dz[B,H,W,C] = relu_mask * (conv_transpose(dy, w) (+ add)), the gradient w.r.t. the OUTPUT of a BatchNorm (+ ReLU) layer
+// whose input was bn_x, plus that BatchNorm's backward sums slices[nslices][2][C] += (sum dz, sum dz * xhat).
+// mask_mode 1: mask = mask_y > 0 (the block output);  2: mask = bf16(bn_x * scale + shift) > 0 (recomputed).
+int mpr_conv_dgrad_bn(const void* dy, const void* w_dgrad, void* dz, const void* add, int mask_mode, const void* mask_y,
+                      const void* bn_x, const float* mean, const float* invstd, const float* scale, const float* shift,
+                      float* slices, int nslices, int prezeroed, int B, int H, int W, int C, int K, int R, int S, int sh,
+                      int sw, int ph, int pw, void* stream) {
+  MPR_REQUIRE(dy && w_dgrad && dz && bn_x && mean && invstd && slices && nslices > 0, "mpr_conv_dgrad_bn: null pointer");
+  MPR_REQUIRE(mask_mode == 1 ? mask_y != nullptr : (mask_mode == 2 && scale && shift), "mpr_conv_dgrad_bn: bad mask mode %d", mask_mode);
+  MPR_REQUIRE(mpr_conv_dgrad_bn_supported(B, H, W, C, K, R, S, sh, sw, ph, pw),
+              "mpr_conv_dgrad_bn: geometry not served (3x3 / stride 1 / pad 1, K %% 64 == 0, enough rows)");
+  MPR_REQUIRE((long long)B * H * W * C < (1ll << 31), "mpr_conv_dgrad_bn: tensor exceeds 2^31 elements");
+  WinBnb bnb = {mask_mode, mask_y, bn_x, mean, invstd, scale, shift, slices, nslices, prezeroed};
+  void* tok = mpr_prof_begin(1, 2.0 * (double)B * H * W * C * 9.0 * K, (hipStream_t)stream);
+  mpr_prof_bytes(tok, 2.0 * ((double)B * H * W * K + 9.0 * C * K + (double)B * H * W * C * (add ? 3 : 2) +
+                             (mask_mode == 1 ? (double)B * H * W * C : 0.0)));
+  const int rc = mpr_win_launch(true, dy, w_dgrad, dz, add, nullptr, B, H, W, K, C, (hipStream_t)stream, &bnb);
+  mpr_prof_end(tok, (hipStream_t)stream);
+  return rc;
 }
 
 }  // extern "C"

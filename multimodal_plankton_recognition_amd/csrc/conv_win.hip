@@ -34,6 +34,13 @@ struct WinParams {
   unsigned src_bytes, wpk_bytes;
   FastDiv div_img, div_wp;
   unsigned long long* probe;   // timing experiments: 8 x uint64 of shader-clock sums per workgroup, or NULL
+  // BatchNorm-backward fusion of a data gradient (template BNB): the result is the gradient w.r.t. a BatchNorm OUTPUT
+  // that went through a ReLU, so the epilogue applies the ReLU mask and accumulates the two BatchNorm-backward sums
+  // (sum dz, sum dz * xhat) into `stats` -- the separate reduce pass over (dy, y, x) disappears.
+  int mask_mode;               // 1: mask = mask_y > 0;  2: mask = bf16(bn_x * scale + shift) > 0 (ReLU mask recomputed)
+  const bf16_t* mask_y;        // [B,H,W,Nout] (mode 1)
+  const bf16_t* bn_x;          // [B,H,W,Nout] BatchNorm input: xhat = (bn_x - mean) * invstd
+  const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;   // [Nout]
 };
 
 __device__ __forceinline__ int win_swz(int row, int chunk) {   // byte offset in a [rows][128 B] image
@@ -51,8 +58,8 @@ __device__ __forceinline__ void wait_vmcnt_win() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int STAGES, bool DGRAD, bool ADD = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams p) {
+template <int WM, int WN, int TM, int TN, int STAGES, bool DGRAD, bool ADD = false, bool BNB = false>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && !BNB ? 4 : 2)) void conv_win_kernel(const WinParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WM * WN, T = 64 * NW;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -236,6 +243,40 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams 
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  // BatchNorm-backward fusion: this thread's 8 channels are fixed (ncol), so are their coefficients
+  float bmu[8], bis[8], bsc[8], bsh[8];
+  if (BNB) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = col_ok ? ncol + e : 0;
+      bmu[e] = p.bn_mean[n];
+      bis[e] = p.bn_invstd[n];
+      bsc[e] = p.mask_mode == 2 ? p.bn_scale[n] : 0.f;
+      bsh[e] = p.mask_mode == 2 ? p.bn_shift[n] : 0.f;
+    }
+  }
+  // dz = mask * q (q: the bf16-rounded gradient values), sums of dz and dz * xhat; returns the masked, re-packed group.
+  // xv / yv: this group of the BatchNorm input / of the mask source, loaded by the caller (all rows at once: the loop
+  // is latency-bound otherwise)
+  auto bnb_group = [&](float* q, const uint4& xv, const uint4& yv) -> uint4 {
+    float xf[8];
+    unpack8(xv, xf);
+    if (p.mask_mode == 1) {
+      float ym[8];
+      unpack8(yv, ym);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[e] = ym[e] > 0.f ? q[e] : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[e] = round_bf16(fmaf(xf[e], bsc[e], bsh[e])) > 0.f ? q[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s1[e] += q[e];
+      s2[e] += q[e] * (xf[e] - bmu[e]) * bis[e];
+    }
+    return pack8(q);
+  };
   if (!ADD) {
     // No residual: the tile is rounded to bf16 IN REGISTERS and staged as bf16 (half the LDS bytes), every wave writing
     // its own rows at once -- one pass of 256 rows at BN = 64, two of 128 rows at BN = 128 (LDS capacity) -- and the
@@ -286,15 +327,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams 
         const bool ok = col_ok && G < p.Gtot && hh < (uint32_t)p.H && ww < (uint32_t)p.W;
         pix[n] = ok ? (b * p.H + hh) * p.W + ww : 0xFFFFFFFFu;
       }
+      uint4 xv[BNB ? NR : 1], yv[BNB ? NR : 1];
+      if (BNB) {
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          const size_t o = (size_t)(pix[n] != 0xFFFFFFFFu ? pix[n] : 0u) * p.Nout + (col_ok ? ncol : 0);
+          xv[n] = *reinterpret_cast<const uint4*>(p.bn_x + o);
+          yv[n] = p.mask_mode == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
+        }
+      }
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
         if (pix[n] != 0xFFFFFFFFu) {
-          *reinterpret_cast<uint4*>(p.dst + (size_t)pix[n] * p.Nout + ncol) = pk[n];
-          if (p.stats) {
+          const size_t o = (size_t)pix[n] * p.Nout + ncol;
+          if (BNB) {
             float q[8];
             unpack8(pk[n], q);
+            *reinterpret_cast<uint4*>(p.dst + o) = bnb_group(q, xv[n], yv[n]);
+          } else {
+            *reinterpret_cast<uint4*>(p.dst + o) = pk[n];
+            if (p.stats) {
+              float q[8];
+              unpack8(pk[n], q);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+              for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+            }
           }
         }
       }
@@ -329,36 +386,55 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_win_kernel(const WinParams 
       }
       win_lds_barrier();
       constexpr int NRA = RPA / RPP;
-#pragma unroll 4
+      // raster decode of all of this thread's rows, then ALL their global loads (residual, BatchNorm input, mask) in one
+      // burst, then the LDS reads and the arithmetic: one exposed latency per pass instead of one per row
+      uint32_t pixa[NRA];
+#pragma unroll
       for (int n = 0; n < NRA; ++n) {
-        const int r = rr + n * RPP;
-        const int G = G0 + ep * RPA + r;
-        bool row_ok = G < p.Gtot;
-        uint32_t pix = 0;
-        if (row_ok) {
-          const uint32_t b = fdiv(G, p.div_img);
-          const uint32_t pp = G - b * p.img;
-          const uint32_t hh = fdiv(pp, p.div_wp);
-          const uint32_t ww = pp - hh * p.Wp;
-          row_ok = hh < (uint32_t)p.H && ww < (uint32_t)p.W;
-          pix = (b * p.H + hh) * p.W + ww;
+        const int G = G0 + ep * RPA + rr + n * RPP;
+        const uint32_t Gc = G < p.Gtot ? G : 0;
+        const uint32_t b = fdiv(Gc, p.div_img);
+        const uint32_t pp = Gc - b * p.img;
+        const uint32_t hh = fdiv(pp, p.div_wp);
+        const uint32_t ww = pp - hh * p.Wp;
+        const bool ok = col_ok && G < p.Gtot && hh < (uint32_t)p.H && ww < (uint32_t)p.W;
+        pixa[n] = ok ? (b * p.H + hh) * p.W + ww : 0xFFFFFFFFu;
+      }
+      uint4 av[NRA], xv[BNB ? NRA : 1], yv[BNB ? NRA : 1];
+#pragma unroll
+      for (int n = 0; n < NRA; ++n) {
+        const size_t o = (size_t)(pixa[n] != 0xFFFFFFFFu ? pixa[n] : 0u) * p.Nout + (col_ok ? ncol : 0);
+        av[n] = *reinterpret_cast<const uint4*>(p.add + o);
+        if (BNB) {
+          xv[n] = *reinterpret_cast<const uint4*>(p.bn_x + o);
+          yv[n] = p.mask_mode == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
         }
-        if (row_ok && col_ok) {
+      }
+#pragma unroll
+      for (int n = 0; n < NRA; ++n) {
+        if (pixa[n] != 0xFFFFFFFFu) {
+          const int r = rr + n * RPP;
           const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
           const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
           float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          const size_t o = (size_t)pix * p.Nout + ncol;
+          const size_t o = (size_t)pixa[n] * p.Nout + ncol;
           float g[8];
-          unpack8(*reinterpret_cast<const uint4*>(p.add + o), g);
+          unpack8(av[n], g);
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] += g[e];
           const uint4 pk = pack8(f);
-          *reinterpret_cast<uint4*>(p.dst + o) = pk;
-          if (p.stats) {
+          if (BNB) {
             float q[8];
             unpack8(pk, q);
+            *reinterpret_cast<uint4*>(p.dst + o) = bnb_group(q, xv[n], yv[n]);
+          } else {
+            *reinterpret_cast<uint4*>(p.dst + o) = pk;
+            if (p.stats) {
+              float q[8];
+              unpack8(pk, q);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+              for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+            }
           }
         }
       }
@@ -649,6 +725,14 @@ extern "C" int mpr_conv_set_window(int on) {   // tuning / test knob; returns th
   return old;
 }
 
+struct WinBnb {   // BatchNorm-backward fusion of a data gradient (see WinParams), shared with conv_igemm.hip
+  int mask_mode;
+  const void *mask_y, *bn_x;
+  const float *mean, *invstd, *scale, *shift;
+  float* slices;
+  int nslices, prezeroed;
+};
+
 extern "C" {   // (internal to the library: declared in conv_igemm.hip, not in the public header)
 
 // Is (geometry, size) served by the shifted-window kernel?  Shared by the launchers and the stat-row query.
@@ -675,12 +759,20 @@ int mpr_win_stat_rows(int B, int H, int W, int Nout) {
 
 // src [B,H,W,srcC] (*) panel [Npad128][9*srcC] -> dst [B,H,W,Nout]  (dgrad: mirrored tap shifts)
 int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, const void* add, float* stats, int B, int H,
-                   int W, int srcC, int Nout, hipStream_t st) {
+                   int W, int srcC, int Nout, hipStream_t st, const WinBnb* bnb) {
   WinParams p;
   p.src = (const bf16_t*)src; p.wpk = (const bf16_t*)wpk; p.dst = (bf16_t*)dst; p.add = (const bf16_t*)add;
   p.stats = stats;
   p.stat_slices = (stats && !dgrad) ? mpr_conv_stat_slices() : 0;
-  {
+  p.mask_mode = 0; p.mask_y = nullptr; p.bn_x = nullptr;
+  p.bn_mean = p.bn_invstd = p.bn_scale = p.bn_shift = nullptr;
+  if (bnb) {
+    // data gradient with the BatchNorm-backward reduction fused in: the sums go to `slices` rows (fp32 atomics)
+    p.stats = bnb->slices; p.stat_slices = bnb->nslices;
+    p.mask_mode = bnb->mask_mode; p.mask_y = (const bf16_t*)bnb->mask_y; p.bn_x = (const bf16_t*)bnb->bn_x;
+    p.bn_mean = bnb->mean; p.bn_invstd = bnb->invstd; p.bn_scale = bnb->scale; p.bn_shift = bnb->shift;
+    if (!bnb->prezeroed) MPR_HIP(hipMemsetAsync(p.stats, 0, sizeof(float) * 2 * (size_t)p.stat_slices * Nout, st));
+  } else {
     const bool prezeroed = mpr_conv_take_prezeroed();
     if (p.stat_slices > 0 && !prezeroed)
       MPR_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)p.stat_slices * Nout, st));
@@ -700,7 +792,7 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
   p.ntn = ceil_div(Nout, BN);
   const int tiles_m = ceil_div(p.Gtot, 256);
   const size_t wbytes = (size_t)((p.wrows + 7) / 8 * 8) * 128;
-  if (win_persistent(dgrad, Nout, add)) {
+  if (!bnb && win_persistent(dgrad, Nout, add)) {
     p.ntn = 1;
     const size_t lds = wbytes + 2 * 8192 + 4 * 4096;
     const int grid_p = tiles_m < 512 ? tiles_m : 512;
@@ -719,6 +811,30 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
       conv_win_persist_kernel<false><<<grid_p, 256, lds, st>>>(p);
     }
     MPR_LAUNCH_CHECK("conv_win_persist_kernel");
+    return MPR_OK;
+  }
+  if (bnb) {
+    // default tiles only: 256 x 64 on 4 waves / 4-deep ring (N <= 64), 256 x 128 on 8 waves / 2-deep ring
+    const int BNt = Nout > 64 ? 128 : 64;
+    p.ntn = ceil_div(Nout, BNt);
+    dim3 gridb(tiles_m * p.ntn);
+#define MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_)                                                            \
+  do {                                                                                                     \
+    static bool attr_set = false;                                                                          \
+    if (!attr_set) {                                                                                       \
+      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, true>,         \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      attr_set = true;                                                                                     \
+    }                                                                                                      \
+    const size_t ring_ = wbytes + (size_t)ST_ * (WN_ * TN_ * 32) * 128;                                    \
+    const size_t epi_ = !ADD_ ? 0 : (size_t)((WN_ * TN_ * 32) == 64 ? 256 : 64) * ((WN_ * TN_ * 32) * 4 + 16); \
+    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, true>                                             \
+        <<<gridb, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                                    \
+  } while (0)
+    if (BNt == 64) { if (add) MPR_WINB(4, 1, 2, 2, 4, true); else MPR_WINB(4, 1, 2, 2, 4, false); }
+    else           { if (add) MPR_WINB(4, 2, 2, 2, 2, true); else MPR_WINB(4, 2, 2, 2, 2, false); }
+#undef MPR_WINB
+    MPR_LAUNCH_CHECK("conv_win_kernel (BatchNorm-backward fusion)");
     return MPR_OK;
   }
   const size_t lds_pad = (g_win_variant & 16) ? 40 * 1024 : 0;   // experiment: force one workgroup per CU

@@ -14,7 +14,7 @@ from typing import Dict
 import torch
 from torch import Tensor, nn
 
-from .layers import BasicBlock, BatchNormParams, PoolTailFn, StemFn
+from .layers import BasicBlock, BatchNormParams, PoolTailFn, StemFn, chain_blocks
 from .ops import ConvGeom, to_krsc_
 
 _RESNETS = {'resnet10t': None, 'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3), 'resnet14': (1, 2, 2, 1),
@@ -46,6 +46,7 @@ class ResNetBackbone(nn.Module):
                 if isinstance(m, BasicBlock):
                     nn.init.zeros_(m.bn2.weight)
         to_krsc_(self)          # block filters: [K][R][S][C] memory (state_dict / logical shapes unchanged)
+        self._chain = chain_blocks(blk for li in range(1, 5) for blk in getattr(self, f'layer{li}'))
 
     def forward_features(self, image: Tensor) -> Tensor:
         """fp32 [B, in_chans, H, W] -> channels-last bf16 [B, H/32, W/32, 512]."""
@@ -53,6 +54,7 @@ class ResNetBackbone(nn.Module):
         x = image.float()
         x = x.reshape(B, H, W, 1) if C == 1 else x.permute(0, 2, 3, 1)
         x = x.contiguous()
+        self._chain.clear()
         out = StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
         for li in range(1, 5):
             for blk in getattr(self, f'layer{li}'):

@@ -152,6 +152,11 @@ class BasicBlockFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd, b1, b2, bd)
             ctx.misc = (st1, st2, std, c1, c2, cd, wd1, wd2, wdd)
+            ctx.chain = mod.chain
+            if mod.chain is not None and mod.feeds_block:
+                # `out` feeds exactly one consumer, the next BasicBlock: its backward may fuse this block's bn2 reduction
+                # into the data gradient that produces d(out) (ops.conv_dgrad_bn)
+                mod.chain.note_bn2(out, x2, st2)
         return out
 
     @staticmethod
@@ -161,13 +166,26 @@ class BasicBlockFn(torch.autograd.Function):
         x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd, b1, b2, bd = ctx.saved_tensors
         st1, st2, std, c1, c2, cd, wd1, wd2, wdd = ctx.misc
         dout = dout.contiguous()
+        chain = ctx.chain
+        if chain is not None:
+            chain.take_note(out)          # (a note nobody used must not outlive this pass)
         # out = relu(bn2(x2) + identity):  dz = dout * (out > 0) feeds bn2 AND the shortcut
-        dx2, dg2, db2, dz = ops.bn_bwd(dout, out, x2, g2, st2, MASK_Y, want_dz=True, beta=b2)
+        sums2 = chain.take_sums(dout) if chain is not None else None
+        if sums2 is not None:
+            # the consumer's data gradient already masked d(out) and left bn2's backward sums: one pass instead of two
+            dz = dout
+            dx2, dg2, db2 = ops.bn_bwd_from_sums(dz, x2, g2, st2, sums2, beta=b2)
+        else:
+            dx2, dg2, db2, dz = ops.bn_bwd(dout, out, x2, g2, st2, MASK_Y, want_dz=True, beta=b2)
         dw2 = ops.conv_wgrad(a1, dx2, c2, w2)
-        da1 = ops.conv_dgrad(dx2, wd2, c2, a1.shape)
         # a1 = bf16(relu(x1*scale+shift)) has no residual: its ReLU mask is recomputed from x1 (bit-identical to
-        # a1 > 0) instead of re-reading a1 in both backward passes
-        dx1, dg1, db1, _ = ops.bn_bwd(da1, None, x1, g1, st1, MASK_RECOMPUTE, beta=b1)
+        # a1 > 0) -- inside the data gradient's epilogue together with bn1's backward sums where the kernel allows it
+        fused1 = ops.conv_dgrad_bn(dx2, wd2, c2, a1.shape, x1, st1, 2)
+        if fused1 is not None:
+            dx1, dg1, db1 = ops.bn_bwd_from_sums(fused1[0], x1, g1, st1, fused1[1], beta=b1)
+        else:
+            da1 = ops.conv_dgrad(dx2, wd2, c2, a1.shape)
+            dx1, dg1, db1, _ = ops.bn_bwd(da1, None, x1, g1, st1, MASK_RECOMPUTE, beta=b1)
         dw1 = ops.conv_wgrad(x, dx1, c1, w1)
         if wd is not None:
             dxd, dgd, dbd, _ = ops.bn_bwd(dz, None, xd, gd, std, MASK_NONE, beta=bd)
@@ -176,7 +194,15 @@ class BasicBlockFn(torch.autograd.Function):
         else:
             dgd = dbd = dwd = None
             skip = dz
-        dx = ops.conv_dgrad(dx1, wd1, c1, x.shape, add=skip)      # skip-connection gradient fused in the epilogue
+        # d(x) = conv1's data gradient + the skip-connection gradient (fused in the epilogue).  x is the previous block's
+        # output: if that block left a note, its ReLU mask and bn2 sums are fused in as well
+        note = chain.take_note(x) if chain is not None else None
+        fused0 = ops.conv_dgrad_bn(dx1, wd1, c1, x.shape, note[0], note[1], 1, mask_y=x, add=skip) if note else None
+        if fused0 is not None:
+            dx = fused0[0]
+            chain.offer_sums(dx, fused0[1])
+        else:
+            dx = ops.conv_dgrad(dx1, wd1, c1, x.shape, add=skip)
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None
 
 
@@ -195,6 +221,9 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(conv(in_channels, out_channels, 1, stride, 0, bias=False),
                                             BatchNormParams(out_channels))
         self.stride = stride
+        # set by the backbone (layers.chain_blocks): its blocks share a hand-off table, and every block but the last feeds
+        # the next BasicBlock and nothing else
+        self.chain, self.feeds_block = None, False
         self.geom1 = ConvGeom(tuple(self.conv1.weight.shape), stride, 1)
         self.geom2 = ConvGeom(tuple(self.conv2.weight.shape), 1, 1)
         self.geomd = ConvGeom(tuple(self.downsample[0].weight.shape), stride, 0) if downsample else None
@@ -206,6 +235,17 @@ class BasicBlock(nn.Module):
                                   ds[0].weight if ds is not None else None,
                                   ds[1].weight if ds is not None else None,
                                   ds[1].bias if ds is not None else None, self)
+
+
+def chain_blocks(blocks):
+    """Declare `blocks` a strict chain (each block's output is consumed by the next block and by nothing else): their
+    backward passes may then hand BatchNorm-backward sums to each other (ops.BlockChain).  Returns the shared table; the
+    owner clears it at the start of every forward pass."""
+    chain = ops.BlockChain()
+    blocks = list(blocks)
+    for i, blk in enumerate(blocks):
+        blk.chain, blk.feeds_block = chain, i + 1 < len(blocks)
+    return chain
 
 
 # ================================================================================================ pool + tail

@@ -647,6 +647,75 @@ def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False, beta=None):
     return dx, (dgamma if ret else None), (dbeta if ret else None), dz
 
 
+# ---- BatchNorm-backward reduction fused into the producing data gradient (csrc/conv_win.hip, template BNB) --------
+# The gradient w.r.t. a BatchNorm(+ReLU) output is produced by a data-gradient convolution; its epilogue can apply the
+# ReLU mask and accumulate (sum dz, sum dz * xhat) itself, so bn_bwd's reduce pass over (dy, y, x) disappears and the
+# apply pass reads the already masked dz.  Inside a BasicBlock (conv2's data gradient -> bn1) this is local; ACROSS
+# blocks (conv1's data gradient + skip of block k+1 -> bn2 of block k) the producer block's forward leaves a note for the
+# consumer's backward and the consumer leaves the sums for the producer's backward -- both keyed by the tensor's storage
+# and valid for one backward pass of one forward pass only.
+DGRAD_BN_FUSION = os.environ.get('MPR_DGRAD_BN_FUSION', '1') != '0'
+
+
+class BlockChain:
+    """Per-backbone hand-off between the autograd Functions of consecutive BasicBlocks.  Entries hold strong references
+    to the tensors they describe (so a matching data_ptr IS that tensor) and are dropped at the backbone's next forward."""
+
+    def __init__(self):
+        self.notes = {}      # data_ptr of a block output -> (out, x2, BNState): "whoever computes d(out) may fuse my bn2 sums"
+        self.sums = {}       # data_ptr of a gradient -> (dz, slices): "this gradient is already masked, here are its sums"
+
+    def clear(self):
+        self.notes.clear()
+        self.sums.clear()
+
+    def note_bn2(self, out, x2, st2):
+        if DGRAD_BN_FUSION:
+            self.notes[out.data_ptr()] = (out, x2, st2)
+
+    def take_note(self, x):
+        n = self.notes.pop(x.data_ptr(), None)
+        if n is None or n[0].shape != x.shape:
+            return None
+        return n[1], n[2]
+
+    def offer_sums(self, dz, slices):
+        self.sums[dz.data_ptr()] = (dz, slices)
+
+    def take_sums(self, dout):
+        n = self.sums.pop(dout.data_ptr(), None)
+        if n is None or n[0].shape != dout.shape:
+            return None
+        return n[1]
+
+
+def conv_dgrad_bn(dy, wd, g, x_shape, bn_x, st, mask_mode, mask_y=None, add=None):
+    """Data gradient with the ReLU mask and the BatchNorm-backward sums of the layer that produced its input fused into
+    the epilogue.  -> (dz, slices [FIN_SLICES, 2, C]) or None when the geometry is not served."""
+    if not DGRAD_BN_FUSION or st.mean is None:
+        return None
+    B, H, W, C = (x_shape[0], 1, x_shape[1], x_shape[2]) if len(x_shape) == 3 else tuple(x_shape)
+    if C > 512 or not N.query('mpr_conv_dgrad_bn_supported', B, H, W, C, g.K, *g.tail):
+        return None
+    dz = torch.empty(x_shape, dtype=BF16, device=dy.device)
+    slices, zeroed = _slice_rows(C, dy.device)
+    N.call('mpr_conv_dgrad_bn', dy, wd, dz, add, mask_mode, mask_y, bn_x, st.mean, st.invstd, st.scale, st.shift, slices,
+           FIN_SLICES, int(zeroed), B, H, W, C, g.K, *g.tail)
+    return dz, slices
+
+
+def bn_bwd_from_sums(dz, x, gamma, st, slices, beta=None):
+    """BatchNorm backward when dz (already ReLU-masked) and its sums are given: ONE pass, dx = k1 dz + k2 x + k3.
+    -> dx, dgamma, dbeta (None when accumulated into the optimizer's buffers)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dgamma, dbeta, acc, ret = _bn_grad_targets(gamma, beta, C, x.device)
+    dx = torch.empty_like(x)
+    N.call('mpr_bn_bwd_apply_fin', dz, None, x, slices, slices.shape[0], rows, gamma.detach(), st.mean, st.invstd,
+           dgamma, dbeta, acc, st.scale, st.shift, MASK_NONE, dx, None, rows, C)
+    return dx, (dgamma if ret else None), (dbeta if ret else None)
+
+
 # ------------------------------------------------------------------------------------------ pooling
 def _pool_geom(x, k, s, p):
     B, H, W, C = _geom(x)

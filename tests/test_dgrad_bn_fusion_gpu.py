@@ -1,0 +1,102 @@
+"""BatchNorm-backward reduction fused into the data-gradient epilogue (csrc/conv_win.hip template BNB, ops.conv_dgrad_bn,
+layers.chain_blocks): chains of BasicBlocks (timm BasicBlock; src/profile_encoder.py:132-148 is the same block in 1-D)
+with the fusion on must give what the unfused kernels give (same arithmetic, different summation order of the BatchNorm
+sums) and what the oracle with bf16-storage emulation gives."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel_l2(got, ref):
+    got, ref = got.detach().float().cpu(), torch.as_tensor(ref).detach().float().cpu()
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-12))
+
+
+def _chain(specs, seed=0):
+    from multimodal_plankton_recognition_amd.layers import BasicBlock, chain_blocks
+    from multimodal_plankton_recognition_amd.ops import to_krsc_
+    torch.manual_seed(seed)
+    blocks = torch.nn.Sequential(*[BasicBlock(2, cin, cout, stride, downsample=(stride != 1 or cin != cout))
+                                   for cin, cout, stride in specs])
+    with torch.no_grad():
+        for n, p in blocks.named_parameters():
+            if p.dim() == 1:
+                p.copy_(torch.rand_like(p) + 0.5 if n.endswith('weight') else torch.rand_like(p) - 0.5)
+    to_krsc_(blocks)
+    return blocks, chain_blocks(blocks)
+
+
+CASES = [([(64, 64, 1), (64, 64, 1), (64, 64, 1)], (4, 12, 12)),          # 256 x 64 tile, notes used twice
+         ([(128, 128, 1), (128, 128, 1)], (3, 10, 14)),                   # 256 x 128 tile
+         ([(64, 64, 1), (64, 128, 2), (128, 128, 1)], (4, 12, 12)),       # a stride-2 consumer leaves the note unused
+         ([(256, 256, 1), (256, 256, 1)], (2, 7, 9))]
+
+
+@pytest.mark.parametrize('specs,shape', CASES)
+def test_block_chain_fused_vs_unfused_vs_oracle(specs, shape):
+    from multimodal_plankton_recognition_amd import ops, _native as N
+    from oracle.image_encoder import _basic_block_2d
+    from oracle.rounding import emulate_bf16
+    old_rows = N.query('mpr_conv_set_dma_min_rows', 0)          # (tiny maps: let them take the window kernel)
+    try:
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(*shape, specs[0][0], generator=g).to(torch.bfloat16)
+        dout = None
+        res = {}
+        for fused in (True, False):
+            blocks, chain = _chain(specs)
+            sd = {k: v.detach().clone() for k, v in blocks.state_dict().items()}
+            blocks.to(DEV).train()
+            ops.DGRAD_BN_FUSION = fused
+            try:
+                xd = x.to(DEV).requires_grad_(True)
+                chain.clear()
+                out = blocks(xd)
+                if dout is None:
+                    dout = torch.randn(out.shape, generator=g).to(torch.bfloat16)
+                out.backward(dout.to(DEV))
+            finally:
+                ops.DGRAD_BN_FUSION = True
+            assert not chain.notes and not chain.sums            # every hand-off consumed or dropped
+            res[fused] = (out.detach().float().cpu(), xd.grad.float().cpu(),
+                          {n: p.grad.detach().float().cpu() for n, p in blocks.named_parameters()})
+        assert torch.equal(res[True][0], res[False][0])
+        assert rel_l2(res[True][1], res[False][1]) < 2e-3
+        for n in res[False][2]:
+            assert rel_l2(res[True][2][n], res[False][2][n]) < 5e-3, n
+        # oracle (bf16-storage emulation)
+        params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running' not in k}
+        xr = x.float().requires_grad_(True)
+        with emulate_bf16():
+            h = xr.permute(0, 3, 1, 2)
+            for i, (_, _, stride) in enumerate(specs):
+                h = _basic_block_2d(sd, f'{i}.', h, stride, True)
+        h.permute(0, 2, 3, 1).backward(dout.float())
+        # (1-ulp flips accumulate over the blocks of a chain: the single-block Tier-1 test is the tight one)
+        assert rel_l2(res[True][0], h.permute(0, 2, 3, 1)) < 5e-3
+        assert rel_l2(res[True][1], xr.grad) < 5e-2
+        for n, gref in ((k, v.grad) for k, v in params.items()):
+            assert rel_l2(res[True][2][n], gref) < 1e-1, n       # (tiny maps: a handful of ReLU-mask flips show)
+    finally:
+        N.query('mpr_conv_set_dma_min_rows', old_rows)
+
+
+def test_fusion_actually_runs():
+    """The fused entry point is taken on an eligible chain (and only then)."""
+    from multimodal_plankton_recognition_amd import ops, _native as N
+    old_rows = N.query('mpr_conv_set_dma_min_rows', 0)
+    calls = []
+    real = ops.conv_dgrad_bn
+    ops.conv_dgrad_bn = lambda *a, **k: (calls.append(a[6]), real(*a, **k))[1]
+    try:
+        blocks, chain = _chain([(64, 64, 1), (64, 64, 1)])
+        blocks.to(DEV).train()
+        x = torch.randn(4, 12, 12, 64).to(torch.bfloat16).to(DEV).requires_grad_(True)
+        chain.clear()
+        blocks(x).sum().backward()
+    finally:
+        ops.conv_dgrad_bn = real
+        N.query('mpr_conv_set_dma_min_rows', old_rows)
+    assert sorted(calls) == [1, 2, 2]        # bn1 of both blocks (mode 2), bn2 of the first via the second's conv1 (mode 1)
