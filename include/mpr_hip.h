@@ -174,6 +174,9 @@ int mpr_bn_finalize_stats(const float* partials, int nparts, long long count, co
                           float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
 int mpr_bn_eval_coefs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* scale, float* shift, int C, void* stream);
+/* invstd = 1 / sqrt(running_var + eps): with mean = running_mean and count = 0 the backward entry points below treat
+ * the layer as the affine map it is in eval mode (dx = gamma * invstd * dz; dgamma, dbeta as usual) */
+int mpr_bn_eval_invstd(const float* running_var, float eps, float* invstd, int C, void* stream);
 int mpr_bn_apply(const void* x, const float* scale, const float* shift, const void* residual /* may be NULL */,
                  int relu, void* y, long long rows, int C, void* stream);
 /* mask_mode: 0 = dz = dy; 1 = dz = dy * (y > 0); 2 = dz = dy * (x*scale+shift > 0); 3 = dz = dy * silu'(x*scale+shift)

@@ -163,6 +163,11 @@ __global__ void bn_eval_coefs_kernel(const float* __restrict__ gamma, const floa
   }
 }
 
+__global__ void bn_eval_invstd_kernel(const float* __restrict__ rv, float eps, float* __restrict__ invstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) invstd[c] = 1.f / sqrtf(rv[c] + eps);
+}
+
 // standalone statistics pass (for producers without a fused epilogue): partials [grid][2][C]
 __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partials,
                                                        long long nvec, int C) {
@@ -230,11 +235,14 @@ __device__ __forceinline__ void bn_block_finalize(const float* __restrict__ slic
     } else {
       const float sum_dz = (float)s1, sum_dzx = (float)s2;
       const float g = a.gamma ? a.gamma[c] : 1.f, is = a.invstd_in[c], mu = a.mean_in[c];
+      // count <= 0: BatchNorm ran on its RUNNING statistics (eval mode; mean_in / invstd_in are those): an affine
+      // map, dx = gamma * invstd * dz -- the batch-statistics terms vanish
+      const bool ev = a.count <= 0.f;
       const float k1 = g * is;
-      const float k2 = -g * is * is * sum_dzx / a.count;
+      const float k2 = ev ? 0.f : -g * is * is * sum_dzx / a.count;
       lds[0][c] = k1;
       lds[1][c] = k2;
-      lds[2][c] = -g * is * sum_dz / a.count - k2 * mu;
+      lds[2][c] = ev ? 0.f : -g * is * sum_dz / a.count - k2 * mu;
       if (blockIdx.x == 0) {
         if (a.dgamma) a.dgamma[c] = a.accumulate ? a.dgamma[c] + sum_dzx : sum_dzx;
         if (a.dbeta) a.dbeta[c] = a.accumulate ? a.dbeta[c] + sum_dz : sum_dz;
@@ -506,6 +514,14 @@ int mpr_bn_eval_coefs(const float* gamma, const float* beta, const float* runnin
   return MPR_OK;
 }
 
+// invstd = 1 / sqrt(running_var + eps): what an eval-mode BatchNorm's BACKWARD needs beside running_mean
+int mpr_bn_eval_invstd(const float* running_var, float eps, float* invstd, int C, void* stream) {
+  MPR_REQUIRE(running_var && invstd, "mpr_bn_eval_invstd: null pointer");
+  bn_eval_invstd_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(running_var, eps, invstd, C);
+  MPR_LAUNCH_CHECK("bn_eval_invstd_kernel");
+  return MPR_OK;
+}
+
 static int launch_bn_apply(const bf16_t* xp, const float* scale, const float* shift, const bf16_t* rp, int relu,
                            bf16_t* yp, long long nvec, int C, int grid, int BLK, const float* slices, int nsl,
                            const BnFinalizeArgs& a, hipStream_t st) {
@@ -556,6 +572,7 @@ int mpr_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float*
                       int C, void* stream) {
   MPR_REQUIRE(C % 8 == 0 && C / 8 <= 256, "mpr_bn_bwd_reduce: C must be a multiple of 8, <= 2048 (got %d)", C);
   MPR_REQUIRE(mask_mode != MASK_Y || y, "mpr_bn_bwd_reduce: mask_mode 1 needs y");
+  MPR_REQUIRE(dy && x && mean && invstd, "mpr_bn_bwd_reduce: null pointer (dy, x, mean, invstd)");
   const long long nvec = rows * C / 8;
   const int block = cg_block(C / 8), grid = ew_grid(nvec, block);
   hipStream_t st = (hipStream_t)stream;
@@ -575,6 +592,7 @@ int mpr_bn_bwd_reduce_slices(const void* dy, const void* y, const void* x, const
                              int prezeroed, long long rows, int C, void* stream) {
   MPR_REQUIRE(C % 8 == 0 && C / 8 <= 256 && nslices > 0 && slices, "mpr_bn_bwd_reduce_slices: bad arguments (C=%d)", C);
   MPR_REQUIRE(mask_mode != MASK_Y || y, "mpr_bn_bwd_reduce_slices: mask_mode 1 needs y");
+  MPR_REQUIRE(dy && x && mean && invstd, "mpr_bn_bwd_reduce_slices: null pointer (dy, x, mean, invstd)");
   const long long nvec = rows * C / 8;
   const int block = cg_block(C / 8), grid = ew_grid(nvec, block);
   hipStream_t st = (hipStream_t)stream;

@@ -53,8 +53,8 @@ class BatchNormParams(nn.Module):
         self._pending += 1
 
 
-def _bn_coefs(stats, count, bn, train, x=None, defer=False):
-    st = ops.bn_coefs(stats, count, bn, train, x, defer=defer)
+def _bn_coefs(stats, count, bn, train, x=None, defer=False, want_bwd=False):
+    st = ops.bn_coefs(stats, count, bn, train, x, defer=defer, want_bwd=want_bwd)
     if train:
         bn.count_batch()
     return st
@@ -131,25 +131,26 @@ class BasicBlockFn(torch.autograd.Function):
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, mod):
         train = mod.training
         c1, c2, cd = mod.geom1, mod.geom2, mod.geomd
-        need_bwd = train
+        # a backward pass will follow when anything differentiable comes in -- also in eval mode, where BatchNorm is the
+        # affine map of its running statistics (ops.bn_coefs keeps mean / invstd for it when gradients are enabled)
+        need_bwd = any(ctx.needs_input_grad)
         wf1, wd1 = ops.packed_weights(w1, c1, need_bwd)
         wf2, wd2 = ops.packed_weights(w2, c2, need_bwd)
         x1, s1 = ops.conv_fwd(x, wf1, c1, train)
-        st1 = _bn_coefs(s1, _rows(x1), mod.bn1, train, x1, defer=True)     # finalized inside the bn_apply that follows
+        st1 = _bn_coefs(s1, _rows(x1), mod.bn1, train, x1, defer=True, want_bwd=need_bwd)   # finalized inside the bn_apply that follows
         a1 = ops.bn_apply(x1, st1, None, True)
         x2, s2 = ops.conv_fwd(a1, wf2, c2, train)
-        st2 = _bn_coefs(s2, _rows(x2), mod.bn2, train, x2, defer=True)
+        st2 = _bn_coefs(s2, _rows(x2), mod.bn2, train, x2, defer=True, want_bwd=need_bwd)
         if wd is not None:
             wfd, wdd = ops.packed_weights(wd, cd, need_bwd)
             xd, sd = ops.conv_fwd(x, wfd, cd, train)
-            std = _bn_coefs(sd, _rows(xd), mod.downsample[1], train, xd, defer=True)
+            std = _bn_coefs(sd, _rows(xd), mod.downsample[1], train, xd, defer=True, want_bwd=need_bwd)
             identity = ops.bn_apply(xd, std, None, False)
         else:
             xd = std = wdd = None
             identity = x
         out = ops.bn_apply(x2, st2, identity, True)
-        ctx.train = train
-        if train:
+        if need_bwd:
             ctx.save_for_backward(x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd, b1, b2, bd)
             ctx.misc = (st1, st2, std, c1, c2, cd, wd1, wd2, wdd)
             ctx.chain = mod.chain
@@ -161,8 +162,6 @@ class BasicBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        if not ctx.train:
-            raise RuntimeError('backward through an eval-mode BatchNorm block is not implemented')
         x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd, b1, b2, bd = ctx.saved_tensors
         st1, st2, std, c1, c2, cd, wd1, wd2, wdd = ctx.misc
         dout = dout.contiguous()

@@ -420,6 +420,7 @@ def stemf_forward(x, weight, bn, train, want_bwd):
     N.call('mpr_stemf_prep', x, weight.detach(), xb, wp, B, H, W)
     st = BNState()
     st.pending = None
+    st.eval = not train
     st.scale = torch.empty(64, dtype=F32, device=dev)
     st.shift = torch.empty(64, dtype=F32, device=dev)
     pooled = torch.empty(B, H // 4, W // 4, 64, dtype=BF16, device=dev)
@@ -543,16 +544,18 @@ def _consumer_slices(parts):
 class BNState:
     """Per-call BatchNorm coefficients: scale/shift always, mean/invstd in train mode.  `pending`: the statistics are
     still (pre-reduced) partial sums -- the first bn_apply finalizes them inside its own kernel."""
-    __slots__ = ('scale', 'shift', 'mean', 'invstd', 'pending')
+    __slots__ = ('scale', 'shift', 'mean', 'invstd', 'pending', 'eval')
 
 
-def bn_coefs(stats, count, bn, train, x=None, defer=False):
+def bn_coefs(stats, count, bn, train, x=None, defer=False, want_bwd=False):
     """bn: object with weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps.
-    defer=True: the caller promises that the next use of the result is ops.bn_apply (which then finalizes)."""
+    defer=True: the caller promises that the next use of the result is ops.bn_apply (which then finalizes).
+    want_bwd (eval mode only): a backward pass will follow -- keep what the affine map's backward needs."""
     C = bn.weight.shape[0]
     dev = bn.weight.device
     st = BNState()
     st.pending = None
+    st.eval = not train
     st.scale = torch.empty(C, dtype=F32, device=dev)
     st.shift = torch.empty(C, dtype=F32, device=dev)
     if train:
@@ -579,7 +582,17 @@ def bn_coefs(stats, count, bn, train, x=None, defer=False):
         st.mean = st.invstd = None
         N.call('mpr_bn_eval_coefs', bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                float(bn.eps), st.scale, st.shift, C)
+        if want_bwd:
+            # eval-mode BatchNorm inside a differentiated graph: its backward is the affine map's (count 0 below)
+            st.mean = bn.running_mean
+            st.invstd = torch.empty(C, dtype=F32, device=dev)
+            N.call('mpr_bn_eval_invstd', bn.running_var, float(bn.eps), st.invstd, C)
     return st
+
+
+def _bwd_count(st, rows):
+    """Element count for the BatchNorm-backward finalize: 0 marks an eval-mode layer (running statistics)."""
+    return 0 if st.eval else rows
 
 
 def bn_apply(x, st, residual=None, relu=True):
@@ -636,9 +649,11 @@ def bn_bwd(dy, y, x, gamma, st, mask_mode, want_dz=False, beta=None):
     dgamma, dbeta, acc, ret = _bn_grad_targets(gamma, beta, C, dev)
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
+    if st.eval and not direct:
+        raise N.NativeLibraryError('backward through an eval-mode BatchNorm with more than 512 channels is not implemented')
     if direct:
         slices = _consumer_slices(parts)
-        N.call('mpr_bn_bwd_apply_fin', dy, y, x, slices, slices.shape[0], rows, gamma.detach(), st.mean, st.invstd,
+        N.call('mpr_bn_bwd_apply_fin', dy, y, x, slices, slices.shape[0], _bwd_count(st, rows), gamma.detach(), st.mean, st.invstd,
                dgamma, dbeta, acc, st.scale, st.shift, mask_mode, dx, dz, rows, C)
         return dx, (dgamma if ret else None), (dbeta if ret else None), dz
     coef = torch.empty(3, C, dtype=F32, device=dev)
@@ -711,8 +726,8 @@ def bn_bwd_from_sums(dz, x, gamma, st, slices, beta=None):
     rows = x.numel() // C
     dgamma, dbeta, acc, ret = _bn_grad_targets(gamma, beta, C, x.device)
     dx = torch.empty_like(x)
-    N.call('mpr_bn_bwd_apply_fin', dz, None, x, slices, slices.shape[0], rows, gamma.detach(), st.mean, st.invstd,
-           dgamma, dbeta, acc, st.scale, st.shift, MASK_NONE, dx, None, rows, C)
+    N.call('mpr_bn_bwd_apply_fin', dz, None, x, slices, slices.shape[0], _bwd_count(st, rows), gamma.detach(), st.mean,
+           st.invstd, dgamma, dbeta, acc, st.scale, st.shift, MASK_NONE, dx, None, rows, C)
     return dx, (dgamma if ret else None), (dbeta if ret else None)
 
 

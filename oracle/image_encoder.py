@@ -37,9 +37,13 @@ def _basic_block_2d(sd, p, x, stride, train):
     return r(F.relu(out + sc))
 
 
-def resnet_features(sd, image, blocks=(2, 2, 2, 2), train=False, prefix=''):
-    """ResNet BasicBlock backbone, pooled features [B, 512]."""
-    x = r(F.conv2d(r(image), r(sd[prefix + 'conv1.weight']), None, 2, 3))
+def resnet_features(sd, image, blocks=(2, 2, 2, 2), train=False, prefix='', round_stem_conv=False):
+    """ResNet BasicBlock backbone, pooled features [B, 512].  (bf16 emulation: the HIP path's fused stem keeps the conv
+    output in registers -- no rounding there -- and rounds the pooled activation only; `round_stem_conv` restores the
+    rounding point of the unfused stem kernels, which store that map.)"""
+    x = F.conv2d(r(image), r(sd[prefix + 'conv1.weight']), None, 2, 3)
+    if round_stem_conv:
+        x = r(x)
     x = r(F.relu(_bn2d(sd, prefix + 'bn1', x, train)))
     x = F.max_pool2d(x, 3, 2, 1)
     for li, reps in enumerate(blocks, start=1):
