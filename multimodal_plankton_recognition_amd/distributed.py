@@ -93,6 +93,16 @@ class Comm:
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x
 
+    @property
+    def overlaps(self):
+        """Can a collective run beside compute (RCCL: its own stream)?  The gloo rehearsal is synchronous."""
+        return dist.get_backend(self.group) == 'nccl'
+
+    def all_reduce_sum_async(self, x):
+        """Enqueue the all-reduce behind torch's CURRENT stream and return the work handle (work.wait() makes the then
+        current stream wait for it)."""
+        return dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
 
 # ------------------------------------------------------------------------------------------------ math back end
 class HipClipMath:
@@ -236,6 +246,127 @@ def dp_clip(image_emb, profile_emb, logit_scale, comm, math, beta=0.0):
     return loss, d_img, d_prof, dls
 
 
+# ------------------------------------------------------------------------------------------------ gradient buckets
+class GradBuckets:
+    """Bucketed all-reduce of FusedSGD's flat gradient buffer, overlapped with the rest of the backward pass.
+
+    The buffer is laid out in parameter order (image encoder: stem, layer1..4, then projections, profile encoder, loss);
+    backward finishes it back to front.  Each bucket is a contiguous slice; the moment the last parameter of a bucket has
+    had its gradient kernels ENQUEUED (ops.grad_ready_observers: the fused backward Functions report through
+    ops.grad_target, autograd-accumulated gradients through the post-accumulate hook), the bucket's all-reduce is enqueued
+    behind the streams that write it -- the weight-gradient side stream and, through an event, the backward stream -- on
+    RCCL's own stream, so it runs underneath the remaining data-gradient chain.  ResNet-18's layer4 alone is 75 % of the
+    gradient bytes and the FIRST thing backward finishes: its 33.6 MB cross xGMI while layers 3..1 are still computing.
+    Buckets that are not complete when backward ends (parameters of the second encoder stream, parameters without a
+    gradient this step) are reduced in finish(), after every gradient stream has been joined.  Without overlap support
+    (gloo rehearsal) everything happens in finish()."""
+
+    def __init__(self, opt, comm, groups):
+        """groups: lists of parameters, each list contiguous in the optimizer's flat buffer, in any order."""
+        opt._install()
+        self.opt, self.comm = opt, comm
+        self.buckets = []                    # [lo, hi, n_params, ids]
+        covered = set()
+        for params in groups:
+            params = [p for p in params if id(p) in opt.offsets]
+            if not params:
+                continue
+            spans = sorted(opt.offsets[id(p)] for p in params)
+            lo, hi = spans[0][0], (spans[-1][0] + spans[-1][1] + 3) // 4 * 4
+            ids = {id(p) for p in params}
+            inside = {i for i, (o, n) in opt.offsets.items() if lo <= o < hi}
+            if inside != ids:
+                raise ValueError('GradBuckets: a bucket must be a contiguous run of the optimizer\'s parameters')
+            self.buckets.append([lo, hi, len(ids), ids])
+            covered |= ids
+        rest = sorted((o, n) for i, (o, n) in opt.offsets.items() if i not in covered)
+        self.rest = self._runs(rest)
+        self.owner = {i: k for k, b in enumerate(self.buckets) for i in b[3]}
+        self.count, self.sent, self.works, self.pending = [], [], [], []
+        self._observer = self._on_ready
+        self.active = False
+
+    @staticmethod
+    def _runs(spans):
+        runs = []
+        for o, n in spans:
+            hi = (o + n + 3) // 4 * 4
+            if runs and runs[-1][1] == o:
+                runs[-1][1] = hi
+            else:
+                runs.append([o, hi])
+        return runs
+
+    def begin(self):
+        self.count = [set() for _ in self.buckets]
+        self.sent = [False] * len(self.buckets)
+        self.works, self.pending = [], []
+        self.active = True
+        if self._observer not in ops.grad_ready_observers:
+            ops.grad_ready_observers.append(self._observer)
+
+    def _on_ready(self, param):
+        # A report means "this parameter's gradient kernels are ABOUT to be enqueued" (ops.grad_target hands out the
+        # pointer first).  A bucket whose last parameter has reported is therefore launched at the next report from
+        # OUTSIDE it: backward Functions run one after the other and each touches one bucket only, so by then the
+        # Function that completed the bucket has returned and all its launches are in the queues.
+        if not self.active:
+            return
+        k = self.owner.get(id(param))
+        if self.pending and self.comm.overlaps:
+            for j in [j for j in self.pending if j != k]:
+                self._launch(j)
+                self.pending.remove(j)
+        if k is None or self.sent[k]:
+            return
+        self.count[k].add(id(param))
+        if len(self.count[k]) == self.buckets[k][2] and k not in self.pending:
+            self.pending.append(k)
+
+    def _launch(self, k):
+        lo, hi = self.buckets[k][0], self.buckets[k][1]
+        cur = torch.cuda.current_stream()
+        side = ops.wgrad_side_stream_of(cur)
+        if side is not None:
+            # weight gradients of this bucket are queued on the side stream, everything else on the backward stream:
+            # the collective goes behind both (the side stream waits for an event of the backward stream -- it lags anyway)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.works.append(self.comm.all_reduce_sum_async(self.opt.flat_grad[lo:hi]))
+        else:
+            self.works.append(self.comm.all_reduce_sum_async(self.opt.flat_grad[lo:hi]))
+        self.sent[k] = True
+
+    def finish(self):
+        """After backward: join the gradient streams, reduce what is left, wait for what is in flight."""
+        self.active = False
+        self.pending = []
+        ops.join_gradient_streams()
+        g = self.opt.flat_grad
+        for k, b in enumerate(self.buckets):
+            if not self.sent[k]:
+                self.comm.all_reduce_sum(g[b[0]:b[1]])
+        for lo, hi in self.rest:
+            self.comm.all_reduce_sum(g[lo:hi])
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+    def close(self):
+        if self._observer in ops.grad_ready_observers:
+            ops.grad_ready_observers.remove(self._observer)
+
+
+def default_bucket_groups(model):
+    """Image backbone back to front in three buckets (layer4 | layer3 | layer2 + layer1 + stem); the rest of the model
+    (projections, profile encoder, loss) is reduced after backward."""
+    bb = getattr(getattr(model, 'image_encoder', None), 'backbone', None)
+    if bb is None or not hasattr(bb, 'layer4'):
+        return []
+    early = [p for n, p in bb.named_parameters() if not n.startswith(('layer3.', 'layer4.'))]
+    return [list(bb.layer4.parameters()), list(bb.layer3.parameters()), early]
+
+
 # ------------------------------------------------------------------------------------------------ DP step
 class DataParallelStep:
     """zero_grad -> encode (local) -> sharded CLIP / SigLIP (+ MSE) -> backward -> flat SUM all-reduce -> fused SGD."""
@@ -257,6 +388,9 @@ class DataParallelStep:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self._flat = None
         self._views = None
+        self.buckets = None
+        if hasattr(optimizer, 'flat_grad') and os.environ.get('MPR_DP_BUCKETS', '1') != '0':
+            self.buckets = GradBuckets(optimizer, self.comm, default_bucket_groups(model))
 
     def _flat_views(self):
         if self._flat is None:
@@ -274,6 +408,8 @@ class DataParallelStep:
         self.opt.zero_grad()
         if batch.get('buckets', 1) != 1:
             raise NotImplementedError('data-parallel step: buckets must be 1 (the global batch is one bucket)')
+        if self.buckets is not None:
+            self.buckets.begin()
         emb = model.encode(**batch)
         core = self.core
         if self.kind == 'clip':
@@ -292,16 +428,25 @@ class DataParallelStep:
             for p, g in pgrads:
                 p.grad.add_(g.reshape(p.shape))
                 p._mpr_touched = True
-            self.comm.all_reduce_sum(arena)
+            if self.buckets is not None:
+                self.buckets.finish()          # (layer4 / layer3 / ... went out during backward; the rest goes now)
+            else:
+                ops.join_gradient_streams()
+                self.comm.all_reduce_sum(arena)
         else:
             for p, g in pgrads:
                 p.grad = g.reshape(p.shape)
             flat, views = self._flat_views()
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-            torch._foreach_copy_(views, grads)
+            # a parameter that received no gradient keeps grad None (the optimizer then skips it, weight decay included,
+            # as in the single-process step); the graph is the same on every rank, so "has a gradient" is too
+            has = [p.grad is not None for p in self.params]
+            flat.zero_()
+            live = [(v, p.grad) for v, p, h in zip(views, self.params, has) if h]
+            if live:
+                torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
             self.comm.all_reduce_sum(flat)
-            for p, v in zip(self.params, views):
-                p.grad = v
+            for p, v, h in zip(self.params, views, has):
+                p.grad = v if h else None
         self.opt.step()
         model.train_loss.append(loss.detach())
         return loss

@@ -137,6 +137,12 @@ def packed_weights(weight, geom, need_dgrad=True):
     return wf, wd
 
 
+# Observers of "the gradient of this parameter has been enqueued" (data-parallel training launches the all-reduce of a
+# bucket of the flat gradient buffer as soon as its last parameter reports in: distributed.GradBuckets).  Called with the
+# parameter, on the host, from inside the backward pass.
+grad_ready_observers = []
+
+
 def grad_target(param):
     """The optimizer-owned gradient memory of `param` (FusedSGD: a view of its flat buffer with the parameter's
     strides, zeroed by zero_grad) or None.  A backward that finds one ACCUMULATES into it and hands autograd None."""
@@ -144,6 +150,8 @@ def grad_target(param):
     if tgt is not None:
         param._mpr_touched = True
         _note_arena_stream(tgt.device.index)
+        for obs in grad_ready_observers:
+            obs(param)
     return tgt
 
 
@@ -197,6 +205,12 @@ def _wgrad_stream(dev):
             low = 0
         side = _wgrad_side[h] = (torch.cuda.current_stream(), torch.cuda.Stream(priority=low))
     return side
+
+
+def wgrad_side_stream_of(stream):
+    """The weight-gradient side stream attached to `stream` (None when none has been created)."""
+    pair = _wgrad_side.get(stream.cuda_stream)
+    return pair[1] if pair is not None else None
 
 
 # ------------------------------------------------------------------------------------------ conv
@@ -853,6 +867,8 @@ def scale_by_scalar(x, s):
 # ------------------------------------------------------------------------------------------ optimiser
 def _mark_touched(p):
     p._mpr_touched = True
+    for obs in grad_ready_observers:
+        obs(p)
 
 
 def _dense(t):
@@ -889,7 +905,7 @@ class FusedSGD:
         self._views = None
         self._arena_key = None
         self._table_full = None
-        self._seen = set()        # ids of parameters that have taken a step (momentum buffer initialised)
+        self._seen = set()        # indices (in self.params) of parameters that have taken a step (momentum buffer initialised)
 
     # ------------------------------------------------------------------ flat buffers
     def _install(self):
@@ -923,6 +939,7 @@ class FusedSGD:
             self.bufs[id(p)] = b
             rows.append([p.data_ptr(), v.data_ptr(), b.data_ptr(), p.numel()])
         self._rows = rows
+        self.offsets = dict((id(p), (o, p.numel())) for p, o in zip(ps, offs))      # parameter -> (offset, numel) in flat_grad
         self._table_full = torch.tensor(rows, dtype=torch.int64).to(dev)
         self._max_numel = max(p.numel() for p in ps)
         self._arena_key = key
@@ -985,5 +1002,26 @@ class FusedSGD:
 
     def state_dict(self):
         return {'steps': self.steps, 'momentum_buffers': [self.bufs.get(id(p)) for p in self.params],
+                'seen': [i in self._seen for i in range(len(self.params))],
                 'hyper': dict(lr=self.lr, momentum=self.momentum, dampening=self.dampening,
                               weight_decay=self.weight_decay, nesterov=self.nesterov)}
+
+    def load_state_dict(self, state):
+        """Resume: momentum buffers, step count and hyper-parameters of a state_dict() taken from an optimizer over the
+        same parameter list (torch.optim.SGD.load_state_dict semantics)."""
+        bufs = state['momentum_buffers']
+        if len(bufs) != len(self.params):
+            raise ValueError(f'FusedSGD.load_state_dict: {len(bufs)} momentum buffers for {len(self.params)} parameters')
+        self._install()
+        seen = state.get('seen', [b is not None for b in bufs])
+        with torch.no_grad():
+            for i, (p, b, sn) in enumerate(zip(self.params, bufs, seen)):
+                if b is not None:
+                    if tuple(b.shape) != tuple(p.shape):
+                        raise ValueError('FusedSGD.load_state_dict: momentum buffer shape mismatch')
+                    self.bufs[id(p)].copy_(b.to(p.device))
+                if sn:
+                    self._seen.add(i)
+        self.steps = int(state.get('steps', 0))
+        for k, v in state.get('hyper', {}).items():
+            setattr(self, k, type(getattr(self, k))(v))

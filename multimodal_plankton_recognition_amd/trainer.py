@@ -94,6 +94,12 @@ def load_from_checkpoint(model_cls, path, map_location='cpu', **override):
 
 
 class Trainer:
+    """fit() also drives data-parallel training (the reference is single-GPU): launched under torchrun
+    (WORLD_SIZE > 1, one process per GPU) every rank runs this loop on ITS shard of each global batch through
+    distributed.DataParallelStep -- global contrastive loss, bucketed gradient all-reduce over RCCL -- validation losses
+    are averaged over the ranks (so checkpointing and early stopping decide identically everywhere), and only rank 0
+    writes logs and checkpoints.  The loaders must shard the data (train_multi.py: DistributedSampler)."""
+
     def __init__(self, logger=None, callbacks=(), max_epochs=1000, min_epochs=0, accumulate_grad_batches=1,
                  precision=None, val_check_interval=None, check_val_every_n_epoch=1, log_every_n_steps=50,
                  max_steps=-1, limit_train_batches=None, limit_val_batches=None, device=None, batch_transform=None,
@@ -117,10 +123,25 @@ class Trainer:
         # [new] optional device-side step between the loader and the model: callable(batch_on_device, training) -> batch
         # (augment.DevicePipeline: random crop / flips / resize / noise on cached batches)
         self.batch_transform = batch_transform
+        self.world = int(os.environ.get('WORLD_SIZE', 1))
+        self.rank = int(os.environ.get('RANK', 0))
+        self._comm = None
+
+    @property
+    def is_global_zero(self):
+        return self.rank == 0
 
     def log(self, metrics):
+        if self._comm is not None:
+            # epoch means of the per-rank losses -> mean over ranks: one number on every rank
+            keys = sorted(k for k, v in metrics.items() if k.endswith('_loss') and isinstance(v, (int, float)))
+            if keys:
+                t = torch.tensor([float(metrics[k]) for k in keys], dtype=torch.float64,
+                                 device=self.device if self._comm.overlaps else 'cpu')
+                self._comm.all_reduce_sum(t)
+                metrics = dict(metrics, **{k: float(v) / self.world for k, v in zip(keys, t.tolist())})
         self.callback_metrics.update(metrics)
-        if self.logger is not None:
+        if self.logger is not None and self.is_global_zero:
             self.logger.log_metrics(metrics)
 
     def _to_device(self, batch, training=True):
@@ -131,22 +152,47 @@ class Trainer:
         model.trainer = self
         model.to(self.device)
         self.optimizer = model.configure_optimizers()
+        stepper = None
+        if self.world > 1:
+            from . import distributed as D
+            D.init(self.device)
+            if self.accumulate > 1:
+                raise NotImplementedError('data-parallel training: accumulate_grad_batches must be 1 (one global batch = one '
+                                          'optimizer step; use more ranks or a larger per-rank batch)')
+            stepper = D.DataParallelStep(model, self.optimizer, self.world)
+            self._comm = stepper.comm
         for epoch in range(self.max_epochs):
             self.current_epoch = epoch
+            if hasattr(getattr(train_loader, 'sampler', None), 'set_epoch'):
+                train_loader.sampler.set_epoch(epoch)       # DistributedSampler: a new shuffle, the same on every rank
             model.train()
             self.optimizer.zero_grad()
+            pending = 0                                    # micro-batches accumulated since the last optimizer step
             for i, batch in enumerate(train_loader):
                 if self.limit_train_batches is not None and i >= self.limit_train_batches:
                     break
-                loss = model.training_step(self._to_device(batch), i)
-                (loss / self.accumulate if self.accumulate > 1 else loss).backward()
-                if (i + 1) % self.accumulate == 0:
-                    self.optimizer.step()
-                    self.optimizer.zero_grad()
+                if stepper is not None:
+                    batch = self._to_device(batch)
+                    batch['buckets'] = 1                  # the GLOBAL batch is one contrastive bucket (distributed.py)
+                    stepper.step(batch)
                     self.global_step += 1
-                    if 0 < self.max_steps <= self.global_step:
-                        self.should_stop = True
-                        break
+                else:
+                    loss = model.training_step(self._to_device(batch), i)
+                    (loss / self.accumulate if self.accumulate > 1 else loss).backward()
+                    pending += 1
+                    if pending == self.accumulate:
+                        self.optimizer.step()
+                        self.optimizer.zero_grad()
+                        pending = 0
+                        self.global_step += 1
+                if 0 < self.max_steps <= self.global_step:
+                    self.should_stop = True
+                    break
+            if pending:
+                # Lightning steps on the last batch of an epoch even when the accumulation window is not full
+                self.optimizer.step()
+                self.optimizer.zero_grad()
+                self.global_step += 1
             model.on_train_epoch_end()
             if valid_loader is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
                 model.eval()
@@ -157,7 +203,8 @@ class Trainer:
                         model.validation_step(self._to_device(batch, training=False), i)
                 model.on_validation_epoch_end()
                 for cb in self.callbacks:
-                    cb.on_validation_end(self, model, self.callback_metrics)
+                    if self.is_global_zero or not isinstance(cb, ModelCheckpoint):     # checkpoints: rank 0 only
+                        cb.on_validation_end(self, model, self.callback_metrics)
             if self.should_stop and epoch + 1 >= self.min_epochs:
                 break
         return model

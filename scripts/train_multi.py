@@ -4,9 +4,18 @@ YAML keys, same run naming and checkpoint layout), driving the gfx950-native Mul
     cd scripts && python3 train_multi.py -d <fold dir with train.csv/test.csv> -m ../model_cards/<card>.yaml
 
 New, clearly flagged options: --synthetic N (no dataset on disk: N synthetic pairs per epoch), --max-epochs,
---limit-batches (smoke runs).  Multi-GPU data parallel: launch with torchrun (see bench.py).
+--limit-batches (smoke runs).
+
+[new] Multi-GPU data parallel (the reference is single-GPU): one process per GPU under torchrun,
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        train_multi.py -d <fold> -m <card>
+
+`bs` is then the PER-GPU batch; every rank trains on its shard of each global batch (DistributedSampler), the contrastive
+loss is taken over the global batch (buckets = 1), gradients are all-reduced over RCCL, rank 0 writes logs / checkpoints.
 """
 import argparse
+import os
 import sys
 from pathlib import Path
 
@@ -35,6 +44,11 @@ parser.add_argument("--gpu-augment", action="store_true",
                     help="[new] cache the deterministic transforms per sample and run crop / flips / resize / noise on the GPU")
 args = parser.parse_args()
 
+world, rank = int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('RANK', 0))
+if world > 1:
+    # one process per GPU: pick this rank's device BEFORE anything touches the GPU
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % max(torch.cuda.device_count(), 1))
+
 card = Path(args.modelcard)
 with open(card, 'r') as stream:
     card_dict = yaml.safe_load(stream)
@@ -58,6 +72,8 @@ else:
     test_set = MultiSet(annotation_path=data_path / 'test.csv', image_transforms=ImageTransformTest(target_size),
                         profile_transform=ProfileTransformTest(target_size))
 
+if world > 1:
+    torch.manual_seed(0)                        # identical initial weights on every rank (parameters are replicated)
 model = MultiModel(
     dim_embed=card_dict['dim_embedding'],
     image_encoder_args=card_dict['image_encoder_args'],
@@ -71,13 +87,22 @@ if args.gpu_augment and not args.synthetic:
     multi_collate = cached_collate
     batch_transform = DevicePipeline(model, target_size, card_dict['buckets'])
 
-train_loader = DataLoader(dataset=train_set, batch_size=bs, shuffle=True, num_workers=card_dict['num_workers'],
-                          drop_last=True, collate_fn=multi_collate)
-valid_loader = DataLoader(dataset=test_set, batch_size=bs, shuffle=True, num_workers=card_dict['num_workers'],
-                          drop_last=True, collate_fn=multi_collate)
+if world > 1:
+    from torch.utils.data.distributed import DistributedSampler
+    train_sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True, drop_last=True)
+    valid_sampler = DistributedSampler(test_set, num_replicas=world, rank=rank, shuffle=True, drop_last=True)
+    train_loader = DataLoader(dataset=train_set, batch_size=bs, sampler=train_sampler, num_workers=card_dict['num_workers'],
+                              drop_last=True, collate_fn=multi_collate)
+    valid_loader = DataLoader(dataset=test_set, batch_size=bs, sampler=valid_sampler, num_workers=card_dict['num_workers'],
+                              drop_last=True, collate_fn=multi_collate)
+else:
+    train_loader = DataLoader(dataset=train_set, batch_size=bs, shuffle=True, num_workers=card_dict['num_workers'],
+                              drop_last=True, collate_fn=multi_collate)
+    valid_loader = DataLoader(dataset=test_set, batch_size=bs, shuffle=True, num_workers=card_dict['num_workers'],
+                              drop_last=True, collate_fn=multi_collate)
 
 name = card.name.split('.')[0] + '_' + '_'.join(str(data_path).split('/')[-2:])
-logger = TensorBoardLogger(save_dir=args.logdir, name=name)
+logger = TensorBoardLogger(save_dir=args.logdir, name=name) if rank == 0 else None
 checkpoint = ModelCheckpoint(filename="{epoch}_{valid_loss:.5f}", monitor="valid_loss",
                              save_top_k=card_dict.get('save_top_k', 1), mode="min")
 stopper = EarlyStopping(monitor='valid_loss', min_delta=0.0, patience=card_dict['patience'], check_finite=False,
@@ -90,5 +115,10 @@ trainer = Trainer(log_every_n_steps=len(train_loader), logger=logger, callbacks=
                   limit_train_batches=args.limit_batches, limit_val_batches=args.limit_batches,
                   batch_transform=batch_transform, **trainer_args)
 
-print(f'Training from model card {args.modelcard}')
+if rank == 0:
+    print(f'Training from model card {args.modelcard}')
 trainer.fit(model, train_loader, valid_loader)
+if world > 1:
+    from multimodal_plankton_recognition_amd import distributed as D
+    D.barrier()
+    D.shutdown()

@@ -1,0 +1,105 @@
+"""CPU / gloo, world_size 2: the WHOLE distributed.DataParallelStep (zero_grad -> encode -> sharded contrastive loss ->
+backward -> flat-buffer SUM all-reduce -> optimizer step) against a single-process step on the concatenated global batch.
+
+The HIP encoders need a GPU, so the model here is a test double with the same surface (encode(), loss with the package's
+CLIPLoss / SigLIPLoss parameters, train_loss) built from plain torch layers WITHOUT batch coupling -- then the sharded step
+must reproduce the global step exactly: same loss, same parameters after every step, on both ranks.  The per-rank loss
+arithmetic is the torch double of tests/test_distributed_cpu.py.  (The FusedSGD flat-buffer path of the same class runs
+on the GPU box: tests/test_dp_world2_gpu.py.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+from torch import nn
+
+from oracle import coordination as OC
+from test_distributed_cpu import TorchMath, _free_port
+
+
+class _Double(nn.Module):
+    def __init__(self, method):
+        super().__init__()
+        from multimodal_plankton_recognition_amd.coordination import CLIPLoss, CLIPPlus, SigLIPLoss, SigLIPPlus
+        torch.manual_seed(3)
+        self.image_encoder = nn.Sequential(nn.Linear(12, 16), nn.Tanh(), nn.Linear(16, 8, bias=False))
+        self.profile_encoder = nn.Sequential(nn.Linear(7, 16), nn.Tanh(), nn.Linear(16, 8, bias=False))
+        self.unused = nn.Parameter(torch.ones(3))          # never receives a gradient: must be left alone
+        self.loss = {'clip': CLIPLoss, 'siglip': SigLIPLoss, 'clipplus': lambda: CLIPPlus(beta=.25),
+                     'siglipplus': lambda: SigLIPPlus(beta=.25)}[method]()
+        self.train_loss = []
+
+    def encode(self, image, profile, **kw):
+        return {'image_emb': self.image_encoder(image), 'profile_emb': self.profile_encoder(profile)}
+
+
+def _data(world, b, step):
+    rs = np.random.RandomState(100 + step)
+    return (torch.from_numpy(rs.standard_normal((world * b, 12)).astype(np.float32)),
+            torch.from_numpy(rs.standard_normal((world * b, 7)).astype(np.float32)))
+
+
+def _oracle_loss(method, core, a, p):
+    if method == 'clip':
+        return OC.clip_loss(a, p, core.logit_scale, 1)
+    if method == 'clipplus':
+        return OC.clip_plus(a, p, core.logit_scale, 1, .25)
+    if method == 'siglip':
+        return OC.siglip_loss(a, p, core.logit_scale, core.bias, 1)
+    return OC.siglip_plus(a, p, core.logit_scale, core.bias, 1, .25)
+
+
+def _worker(rank, world, port, b, method, steps, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from multimodal_plankton_recognition_amd import distributed as D
+    torch.set_num_threads(1)
+    D.init(backend='gloo')
+    model = _Double(method)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3, nesterov=True)
+    stepper = D.DataParallelStep(model, opt, world, math=TorchMath())
+    losses = []
+    for s in range(steps):
+        img, prof = _data(world, b, s)
+        sl = slice(rank * b, (rank + 1) * b)
+        losses.append(float(stepper.step({'image': img[sl], 'profile': prof[sl], 'buckets': 1})))
+    out[rank] = (losses, {k: v.detach().numpy().copy() for k, v in model.state_dict().items()})
+    D.barrier()
+    D.shutdown()
+
+
+@pytest.mark.parametrize('method', ['clip', 'siglip', 'clipplus', 'siglipplus'])
+def test_whole_dp_step_world2_equals_global_step(method):
+    world, b, steps = 2, 6, 3
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), b, method, steps, out), nprocs=world, join=True)
+    # single process, global batch
+    model = _Double(method)
+    core = model.loss if method in ('clip', 'siglip') else (model.loss.clip if method == 'clipplus' else model.loss.siglip)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3, nesterov=True)
+    ref_losses = []
+    for s in range(steps):
+        img, prof = _data(world, b, s)
+        opt.zero_grad()
+        emb = model.encode(img, prof)
+        loss = _oracle_loss(method, core, emb['image_emb'], emb['profile_emb'])
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss))
+    ref_sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    for rank in range(world):
+        losses, sd = out[rank]
+        np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+        for k in ref_sd:
+            np.testing.assert_allclose(sd[k], ref_sd[k], rtol=2e-4, atol=2e-6, err_msg=f'rank {rank} {k}')
+        assert np.array_equal(sd['unused'], np.ones(3, np.float32))
+
+
+def test_dp_step_rejects_buckets_and_rank_loss():
+    from multimodal_plankton_recognition_amd import distributed as D
+    from multimodal_plankton_recognition_amd.coordination import RankLoss
+    m = _Double('clip')
+    m.loss = RankLoss(margin=0.25)
+    with pytest.raises(NotImplementedError):
+        D.DataParallelStep(m, torch.optim.SGD(m.parameters(), lr=0.1), 1, comm=object(), math=TorchMath())
