@@ -937,6 +937,10 @@ int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S, int 
 // y[B,P,Q,K] = conv(x[B,H,W,C], w) ; stats (optional): [mpr_conv_fwd_stat_rows][2][K] fp32 partial sums
 int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B, int H, int W, int C,
                  int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+  // the one-shot "slice rows are already zero" promise (mpr_conv_stats_prezeroed) belongs to THIS call: taken before any
+  // argument check can return (it would otherwise stay armed and make a later convolution skip its memset), re-armed
+  // right in front of the launcher that consumes it
+  const bool prezeroed = mpr_conv_take_prezeroed();
   MPR_REQUIRE(x && w_fwd && y, "mpr_conv_fwd: null pointer");
   MPR_REQUIRE(C % 8 == 0 && K % 8 == 0, "mpr_conv_fwd: C (%d) and K (%d) must be multiples of 8", C, K);
   MPR_REQUIRE(sh >= 1 && sw >= 1 && R >= 1 && S >= 1 && ph >= 0 && pw >= 0, "mpr_conv_fwd: bad geometry");
@@ -948,6 +952,7 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
     // 3x3 / stride 1 / pad 1: shifted-window kernel (conv_win.hip)
     void* tok = mpr_prof_begin(0, 2.0 * (double)B * P * Q * K * 9.0 * C, (hipStream_t)stream);
     mpr_prof_bytes(tok, 2.0 * ((double)B * H * W * C + 9.0 * C * K + (double)B * P * Q * K));
+    g_stats_prezeroed = prezeroed;
     const int rc = mpr_win_launch(false, x, w_fwd, y, nullptr, stats, B, H, W, C, K, (hipStream_t)stream, nullptr);
     mpr_prof_end(tok, (hipStream_t)stream);
     return rc;
@@ -960,6 +965,7 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
   p.M = B * P * Q; p.Nout = K; p.Kg = R * S * C; p.Kgpad = pad_to(p.Kg, 64); p.nk = p.Kgpad / 64;
   p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
   p.Pm = P; p.Qm = Q; p.div_pq = make_fastdiv(P * Q); p.div_q = make_fastdiv(Q);
+  g_stats_prezeroed = prezeroed;
   return launch_igemm(false, p, (hipStream_t)stream);
 }
 

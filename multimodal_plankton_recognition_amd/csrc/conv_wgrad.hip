@@ -467,6 +467,11 @@ int mpr_conv_set_wgrad_dma_min_pixels(int pixels) {   // tuning / test knob; ret
 // dw_oihw may be NULL: see below.
 int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oihw, int accumulate, int B,
                    int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+  // the one-shot scratch loan (mpr_conv_set_wgrad_scratch) belongs to THIS call whatever happens next: taken before any
+  // argument check can return, or it would stay armed for an unrelated later call
+  float* scratch = nullptr;
+  long long scratch_floats = 0;
+  mpr_wgw_take_scratch(&scratch, &scratch_floats);
   MPR_REQUIRE(x && dy && workspace, "mpr_conv_wgrad: null pointer");
   MPR_REQUIRE(C % 8 == 0 && K % 8 == 0, "mpr_conv_wgrad: C (%d) and K (%d) must be multiples of 8", C, K);
   const int P = (H + 2 * ph - R) / sh + 1, Q = (W + 2 * pw - S) / sw + 1;
@@ -474,9 +479,6 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   MPR_REQUIRE((long long)B * H * W * C < (1ll << 31) && (long long)B * P * Q * K < (1ll << 31),
               "mpr_conv_wgrad: tensor exceeds 2^31 elements");
   hipStream_t st = (hipStream_t)stream;
-  float* scratch = nullptr;
-  long long scratch_floats = 0;
-  mpr_wgw_take_scratch(&scratch, &scratch_floats);       // one-shot loan for this call (conv_wgrad_win.hip)
   WgradParams p;
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = workspace;
   p.H = H; p.W = W; p.C = C; p.K = K; p.P = P; p.Q = Q; p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;

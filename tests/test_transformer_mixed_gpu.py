@@ -329,3 +329,27 @@ def test_mixed_training_tracks_exact_fp32_training():
     a, b = np.array(curves['32']), np.array(curves['bf16-mixed'])
     assert a[0] != a[-1]
     np.testing.assert_allclose(b, a, rtol=2e-2, err_msg=str(curves))
+
+
+def test_patch_embedding_trains_after_a_no_grad_forward():
+    """A no_grad forward (export / sanity validation) before training must not freeze the cached view of the patch
+    embedding's filter: the weight receives a gradient in the next training pass, and the backbone stays deep-copyable."""
+    import copy
+    from multimodal_plankton_recognition_amd import transformer as TF
+    from multimodal_plankton_recognition_amd.image_encoder import ViTBackbone
+    torch.manual_seed(0)
+    vit = ViTBackbone(embed_dim=64, depth=1, num_heads=1, patch=16, img_size=64, in_chans=1).to(DEV)
+    x = torch.randn(4, 1, 64, 64, device=DEV)
+    old = TF.set_precision('bf16-mixed')
+    try:
+        with torch.no_grad():
+            vit.eval()
+            vit.forward_pooled(x)
+        twin = copy.deepcopy(vit)
+        for m in (vit, twin):
+            m.train()
+            m.forward_pooled(x).sum().backward()
+            g = m.patch_embed.proj.weight.grad
+            assert g is not None and float(g.abs().sum()) > 0
+    finally:
+        TF._PRECISION[0] = old
