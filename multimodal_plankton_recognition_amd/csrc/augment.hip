@@ -3,8 +3,8 @@
 // crop and the Lanczos resize to ceil(1.05 T) are done once when the dataset is cached (host, data.py), everything that is
 // random per step runs here:
 //   image   u8 [B][S][S]  -> random crop T x T, vertical flip, (paired) horizontal flip, /255*2-1      -> fp32 [B][1][T][T]
-//   profile fp32 [B][Lmax][C] raw counts + length -> log1p / ceiling * 2 - 1, linear resize to S samples (align_corners =
-//           False, as F.interpolate), random crop T, + sigma * N(0,1), (paired) time reversal         -> fp32 [B][T][C]
+//   profile fp32 [B][Lmax][C] raw counts + length -> log1p / ceiling * 2 - 1, resize to S samples (anti-aliased bilinear:
+//           torchvision's tensor Resize), random crop T, + sigma * N(0,1), (paired) time reversal         -> fp32 [B][T][C]
 // The random decisions (offsets, flips) are inputs, so a batch is reproducible and testable against the host transforms.
 #include "common.h"
 
@@ -40,17 +40,26 @@ __global__ __launch_bounds__(256) void aug_profile_kernel(const float* __restric
     const int t = (int)(r % T), b = (int)(r / T);
     const int L = length[b];
     const int j = left[b] + (reverse[b] ? T - 1 - t : t);          // sample of the resized profile
+    // torchvision's tensor Resize = interpolate(mode='bilinear', antialias=True) (aten _upsample_bilinear2d_aa): a
+    // triangle filter of half-width max(scale, 1) around scale * (j + 0.5), weights normalised over the taps inside the
+    // signal -- plain bilinear when upscaling, an area-weighted average when the profile is longer than S
     const float scale = (float)L / (float)S;
-    float s = scale * ((float)j + 0.5f) - 0.5f;
-    if (s < 0.f) s = 0.f;
-    const int i0 = (int)s;
-    const int i1 = i0 + (i0 < L - 1 ? 1 : 0);
-    const float l1 = fminf(fmaxf(s - (float)i0, 0.f), 1.f), l0 = 1.f - l1;
+    const float support = scale >= 1.f ? scale : 1.f, invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    const float center = scale * ((float)j + 0.5f);
+    int xmin = (int)(center - support + 0.5f);
+    xmin = xmin < 0 ? 0 : xmin;
+    int xmax = (int)(center + support + 0.5f);
+    xmax = xmax > L ? L : xmax;
     const float* p = raw + (size_t)b * Lmax * C + c;
     const float inv = ceiling[c];
-    const float a0 = logf(p[(size_t)i0 * C] + 1.f) / inv * 2.f - 1.f;
-    const float a1 = logf(p[(size_t)i1 * C] + 1.f) / inv * 2.f - 1.f;
-    float v = l0 * a0 + l1 * a1;
+    float acc = 0.f, wsum = 0.f;
+    for (int i = xmin; i < xmax; ++i) {
+      float w = 1.f - fabsf(((float)i - center + 0.5f) * invscale);
+      w = w > 0.f ? w : 0.f;
+      acc += w * (logf(p[(size_t)i * C] + 1.f) / inv * 2.f - 1.f);
+      wsum += w;
+    }
+    float v = wsum > 0.f ? acc / wsum : 0.f;
     if (sigma > 0.f) {                                              // Box-Muller on two counter hashes
       const uint32_t h1 = ag_mix32(ag_mix32((uint32_t)idx ^ seed) + 0x9e3779b9U * (seed | 1u) + (uint32_t)(idx >> 32));
       const uint32_t h2 = ag_mix32(h1 ^ 0x85ebca6bU);

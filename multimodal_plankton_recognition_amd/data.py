@@ -96,10 +96,15 @@ class ImageTransformTest:
 
 # ------------------------------------------------------------------------------------------------ profile pipeline
 def _profile_base(prof, length):
-    x = torch.as_tensor(np.asarray(prof), dtype=torch.float32).add(1).log()
-    x = x.div(torch.tensor(PROFILE_CEIL[:x.shape[1]])).mul(2).add(-1)          # src/data.py:129
-    x = F.interpolate(x.t().unsqueeze(0), size=length, mode='linear', align_corners=False, antialias=False)
-    return x.squeeze(0)                                                          # [C, length]
+    """log1p / ceiling * 2 - 1, then the reference's ``v2.Resize((1, length))`` on the [C, 1, L] tensor
+    (src/data.py:129-133,149-152): torchvision resizes tensors with ``interpolate(mode='bilinear', antialias=True)`` --
+    a triangle filter whose support grows with the downscaling factor (real profiles are mostly LONGER than the target, so
+    this is an area-weighted average, not a two-point sample); upscaling is plain bilinear.  float64 like the reference
+    (``torch.tensor(ndarray)``), cast to float32 by the caller at the end."""
+    x = torch.as_tensor(np.asarray(prof), dtype=torch.float64).add(1).log()
+    x = x.div(torch.tensor(PROFILE_CEIL[:x.shape[1]], dtype=torch.float64)).mul(2).add(-1)      # src/data.py:129
+    x = F.interpolate(x.t()[None, :, None, :], size=(1, length), mode='bilinear', align_corners=False, antialias=True)
+    return x[0, :, 0, :]                                                         # [C, length]
 
 
 class ProfileTransformTrain:

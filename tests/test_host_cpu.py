@@ -101,3 +101,40 @@ def test_single_modality_cards_build_their_models():
     c2 = yaml.safe_load(open(os.path.join(ROOT, 'model_cards', 'example_image.yaml')))
     im = ImageModel(c2['image_encoder_args'], c2['optim_args'], names)
     assert im.image_encoder.dim_out == 512 + 2
+
+
+def _aa_resize_restated(x, out_len):
+    """numpy restatement of aten::_upsample_bilinear2d_aa along one axis (what torchvision's tensor Resize computes,
+    /root/reference/src/data.py:133,152): triangle filter, half-width max(scale, 1), weights normalised per output."""
+    import numpy as np
+    L = x.shape[-1]
+    scale = L / out_len
+    support = scale if scale >= 1 else 1.0
+    inv = 1.0 / scale if scale >= 1 else 1.0
+    out = np.zeros(x.shape[:-1] + (out_len,))
+    for j in range(out_len):
+        center = scale * (j + 0.5)
+        xmin = max(0, int(center - support + 0.5))
+        xmax = min(L, int(center + support + 0.5))
+        w = np.array([max(0.0, 1.0 - abs((i - center + 0.5) * inv)) for i in range(xmin, xmax)])
+        out[..., j] = (x[..., xmin:xmax] * w).sum(-1) / w.sum()
+    return out
+
+
+@pytest.mark.parametrize('L,T', [(1000, 236), (300, 224), (17, 236), (224, 224), (5, 64)])
+def test_profile_resize_is_torchvisions_antialiased_bilinear(L, T):
+    """The profile resize of ProfileTransformTrain / Test: long profiles are area-averaged (anti-aliasing), short ones
+    plainly interpolated -- against an independent restatement of the filter."""
+    import numpy as np
+    from multimodal_plankton_recognition_amd import data as D
+    rs = np.random.RandomState(L)
+    prof = rs.rand(L, 6) * 2000
+    got = D._profile_base(prof, T).numpy()                                         # [6, T]
+    base = np.log(prof + 1) / np.array(D.PROFILE_CEIL)[None, :] * 2 - 1
+    ref = _aa_resize_restated(base.T, T)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12)
+    if L > 2 * T:                                                                  # really an average: far from 2-point sampling
+        two_point = torch.nn.functional.interpolate(torch.from_numpy(base.T)[None], size=T, mode='linear',
+                                                    align_corners=False)[0].numpy()
+        assert np.abs(got - two_point).max() > 1e-2
+    assert D.ProfileTransformTest(T)(prof).dtype == torch.float32
