@@ -6,8 +6,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with hipEvent pairs around every launch of
-the dominant kernel (conv_igemm_dma_kernel, forward + dgrad instantiations) inside the timed region;
-`cpu_baseline` times the CPU oracle (plain-torch fp32 restatement of the same step) on a bounded sample.
+the dominant kernel family (the shifted-window conv kernel, forward + data-gradient instantiations) inside
+the timed region, `roofline.families` splits the other MFMA kernels the same way; `cpu_baseline` times the
+CPU oracle (plain-torch fp32 restatement of the same step) on the SAME batch-512 workload, a few steps.
 """
 import argparse
 import ctypes
@@ -68,13 +69,16 @@ def isolated_conv_rate(B, dev):
             'avg_launch_us': round(tot_ms * 1e3 / 8, 2)}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (scripts/prof_pmc.sh + scripts/pmc_summary.py run
-    this same command under rocprofv3 --pmc; a process cannot read its own counters), or None."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    if not os.path.exists(path):
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed PMC summary (scripts/prof_pmc.sh + scripts/pmc_summary.py
+    run this same command under rocprofv3 --pmc; a process cannot read its own counters), or None."""
+    if not os.path.exists(PMC_FILE):
         return None
-    return round(json.load(open(path))[kernel]['hbm_bytes_per_launch'])
+    fam = json.load(open(PMC_FILE)).get('families', {}).get(family)
+    return round(fam['hbm_bytes_per_launch']) if fam and fam.get('launches_per_step') else None
 
 
 def host_cores():
@@ -89,33 +93,46 @@ def host_cores():
     return n
 
 
-def cpu_baseline(card, T, threads):
-    """Oracle (CPU restatement) timed on a bounded sample of the same workload: batch 32 instead of 512."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(card, T, threads, B):
+    """Oracle (CPU restatement, torch fp32) timed on the SAME workload as the GPU line: batch B (512), dropout on,
+    1 warm-up + up to 3 timed steps (bounded to ~30 s), median."""
     from oracle import model as OM
     from multimodal_plankton_recognition_amd.model import MultiModel
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    Bc = 32
     model = MultiModel(card['dim_embedding'], card['image_encoder_args'], card['profile_encoder_args'],
                        card['coordination_args'], card['optim_args'])
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     del model
     cfg = {k: card[k] for k in ('image_encoder_args', 'profile_encoder_args', 'coordination_args', 'optim_args')}
-    batch = synthetic_batch(Bc, T, 'cpu', 1234)
+    batch = synthetic_batch(B, T, 'cpu', 1234)
     batch['buckets'] = 1
     bufs = {}
-    OM.train_step(sd, batch, cfg, bufs)                       # warm-up
+    t0 = time.time()
+    OM.train_step(sd, batch, cfg, bufs, apply_dropout=True)                       # warm-up
+    warm = time.time() - t0
     times = []
-    t_end = time.time() + 25.0
-    while len(times) < 5 and (time.time() < t_end or not times):
+    t_end = time.time() + max(30.0 - warm, 0.0)
+    while len(times) < 3 and (time.time() < t_end or not times):
         t0 = time.time()
-        OM.train_step(sd, batch, cfg, bufs)
+        OM.train_step(sd, batch, cfg, bufs, apply_dropout=True)
         times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {'value': round(Bc / med, 2), 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
-            'sample': f'oracle (torch fp32 CPU) full step at batch {Bc} (bounded sample of the batch-512 workload), '
-                      f'median of {len(times)} steps, dropout off'}
+    return {'value': round(B / med, 2), 'unit': 'samples/s', 'cores': threads, 'kind': 'port', 'cpu': cpu_model(),
+            'sample': f'oracle (torch fp32 CPU restatement) full optimisation step at batch {B}, dropout '
+                      f"{card['image_encoder_args'].get('dropout', 0.1)}, 1 warm-up + {len(times)} timed steps, median "
+                      f'{med:.2f} s/step'}
 
 
 def main():
@@ -175,15 +192,18 @@ def main():
     lib = N.lib()
     lib.mpr_prof_reset()
     lib.mpr_prof_enable(1)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries on the step's stream
     if world > 1:
         D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         # the per-launch HIP events of the roofline measurement cost ~5 us of stream bubble each (~0.4 ms per step):
         # they are recorded on every 4th step of the timed region only
         lib.mpr_prof_enable(1 if i % 4 == 0 else 0)
         loss = one_step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         D.barrier()
@@ -192,6 +212,10 @@ def main():
     if world > 1:
         elapsed = D.max_over_ranks(elapsed)
     loss_val = float(loss.detach())
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
+    unprofiled = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps) if i % 4)
+    median_unprofiled = unprofiled[len(unprofiled) // 2] if unprofiled else median_ms
 
     def collect(kind):
         ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
@@ -199,24 +223,40 @@ def main():
         return ms.value, work.value, n.value
 
     if rank == 0:
-        ms_f, w_f, n_f = collect(0)
-        ms_d, w_d, n_d = collect(1)
-        ms_w, w_w, n_w = collect(2)
-        ig_ms, ig_w, ig_n = ms_f + ms_d, w_f + w_d, n_f + n_d
-        ig_bytes = ctypes.c_double()
-        lib.mpr_prof_collect_bytes(0, ctypes.byref(ig_bytes))
-        algo_bytes = ig_bytes.value
-        lib.mpr_prof_collect_bytes(1, ctypes.byref(ig_bytes))
-        algo_bytes += ig_bytes.value
-        traffic = pmc_traffic('conv_igemm_dma_kernel') if c3 else None      # (the committed PMC passes are C3's)
-        achieved = ig_w / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
-        ms_per_step = elapsed / args.steps * 1e3
         prof_steps = len(range(0, args.steps, 4))
+        ms_per_step = elapsed / args.steps * 1e3
+
+        def family(kinds, name, pmc_key, algo_kinds=None):
+            ms = work = 0.0
+            n = 0
+            for k in kinds:
+                a, b, c = collect(k)
+                ms, work, n = ms + a, work + b, n + c
+            by = ctypes.c_double()
+            algo = 0.0
+            for k in kinds:
+                lib.mpr_prof_collect_bytes(k, ctypes.byref(by))
+                algo += by.value
+            ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {'kernel': name, 'achieved': round(ach, 2), 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                    'launches': n, 'avg_launch_us': round(ms * 1e3 / max(n, 1), 2),
+                    'share_of_step_time': round(ms / max(prof_steps, 1) / ms_per_step, 3),
+                    'algorithmic_bytes_per_launch': round(algo / max(n, 1)),
+                    'traffic': pmc_traffic(pmc_key) if c3 else None}
+
+        fam = {'win_fwd': family([6], 'conv_win_kernel / conv_win_persist_kernel, forward (3x3 stride 1)', 'win_fwd'),
+               'win_dgrad': family([7], 'conv_win_kernel, data gradient (+ fused skip add, ReLU mask, BatchNorm-backward sums)', 'win_dgrad'),
+               'dma_fwd_dgrad': family([0, 1], 'conv_igemm_dma_kernel (stride-2 3x3 and 1x1 convolutions, forward + data gradient)', 'dma_fwd_dgrad'),
+               'wgrad_win': family([8], 'conv_wgrad_win_kernel (3x3 stride 1 weight gradients)', 'wgrad_win'),
+               'wgrad_dma': family([2], 'conv_wgrad_dma_kernel (other weight gradients)', 'wgrad_dma')}
+        dom = family([6, 7], 'conv_win_kernel (shifted-window implicit-GEMM conv: forward + data-gradient instantiations, 13 of '
+                             "ResNet-18's 20 convolutions, 80 % of its FLOPs)", 'win_fwd_dgrad')
         out = {
             'metric': 'samples/sec (image+profile pairs) for train_multi', 'value': round(B * world * args.steps / elapsed, 1),
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
+            'ms_per_step_median': round(median_ms, 3), 'ms_per_step_median_unprofiled': round(median_unprofiled, 3),
             'config': {'workload': ('C3: model_cards/resnet18_cnn_2_512_clip.yaml -- ResNet-18 (1x224x224) + ProfileCNN[2,2,2,2] '
                                     '+ CLIP, D=512, full step (fwd+bwd+SGD nesterov), dropout 0.1') if c3 else
                                    (f"{os.path.relpath(args.card, ROOT)} -- {card['image_encoder_args']['name']} + "
@@ -225,26 +265,25 @@ def main():
                        'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'loss': round(loss_val, 5)},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_win_kernel + conv_igemm_dma_kernel (LDS-DMA implicit-GEMM conv, forward + data-gradient instantiations, image branch)',
-                         'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, '
-                                                             'profiles/r01_pmc_traffic.json)',
-                         'algorithmic_bytes_per_launch': round(algo_bytes / max(ig_n, 1)),
-                         'launches': ig_n, 'avg_launch_us': round(ig_ms * 1e3 / max(ig_n, 1), 2),
-                         'share_of_step_time': round(ig_ms / prof_steps / ms_per_step, 3),
-                         'wgrad_kernel': {'name': 'conv_wgrad_win_kernel + conv_wgrad_dma_kernel',
-                                          'achieved': round(w_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
-                                          'launches': n_w, 'share_of_step_time': round(ms_w / prof_steps / ms_per_step, 3)},
+            'roofline': {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['achieved'], 'peak': MFMA_BF16_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': dom['frac'], 'traffic': dom['traffic'],
+                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, '
+                                         'profiles/r02_pmc_traffic.json)',
+                         'algorithmic_bytes_per_launch': dom['algorithmic_bytes_per_launch'],
+                         'launches': dom['launches'], 'avg_launch_us': dom['avg_launch_us'],
+                         'share_of_step_time': dom['share_of_step_time'],
+                         'families': fam,
                          'alone': isolated_conv_rate(B, dev) if c3 else None,
-                         'note': 'achieved / avg_launch_us: event-timed on the launch stream INSIDE the timed steps, i.e. while '
-                                 'the profile branch and the weight-gradient kernels run beside it on other streams; '
-                                 '"alone" is the same kernel on the four ResNet-18 body shapes with the GPU to itself'},
+                         'note': 'achieved / avg_launch_us: hipEvent-timed on the launch stream INSIDE every 4th timed step, i.e. '
+                                 'while the profile branch and the weight-gradient kernels run beside it on other streams; '
+                                 '"alone" is the same kernel on the four ResNet-18 body shapes with the GPU to itself; '
+                                 'ms_per_step is wall clock over all steps, ms_per_step_median the median of per-step HIP '
+                                 'event intervals (ms_per_step_median_unprofiled: steps without per-launch events)'},
         }
         if world == 1 and not args.no_cpu_baseline and c3:
             # host share of a 1-GPU box is 16 cores (the node reports all of them): never oversubscribe
             threads = host_cores()
-            out['cpu_baseline'] = cpu_baseline(card, T, threads)
+            out['cpu_baseline'] = cpu_baseline(card, T, threads, B)
         print(json.dumps(out), flush=True)
     if world > 1:
         D.shutdown()

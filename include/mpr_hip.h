@@ -11,9 +11,13 @@
  *     embeddings, losses and parameters / gradients are fp32 (parameters in torch's own layouts);
  *   - return value: 0 = ok, 1 = invalid argument, 2 = HIP runtime error; mpr_last_error() gives the
  *     message for the calling thread.  Nothing aborts.
- *   - "stat rows": train-mode BatchNorm statistics are produced as per-workgroup partial sums
- *     [rows][2][C] (sum, sum of squares) and reduced by mpr_bn_finalize_stats; the *_stat_rows /
- *     mpr_bn_reduce_rows functions give the number of rows the producer will write.
+ *   - "stat rows": train-mode BatchNorm statistics are partial sums [rows][2][C] (sum, sum of squares).  By default
+ *     the producers ADD into a small fixed number of zeroed slice rows (fp32 atomics, mpr_conv_set_stat_slices: 8) that
+ *     the consuming kernel finalizes itself (mpr_bn_apply_fin, mpr_bn_bwd_apply_fin, mpr_stemf_pool); with slices off they
+ *     write one row per workgroup (bitwise reproducible; the *_stat_rows / mpr_bn_reduce_rows functions give the count)
+ *     for mpr_bn_reduce_partials / mpr_bn_finalize_stats.
+ *   - tuning knobs and timing-experiment hooks (tile variants, kernel on/off switches, in-kernel time stamps, operand
+ *     dropping) are NOT part of this header: include/mpr_hip_debug.h.
  */
 #ifndef MPR_HIP_H
 #define MPR_HIP_H
@@ -28,8 +32,9 @@ const char* mpr_target_arch(void);                 /* "gfx950" */
 const char* mpr_last_error(void);
 void mpr_set_error(const char* fmt, ...);
 int mpr_device_check(char* name, int name_len);    /* 0 iff device 0 is gfx950; name: HOST buffer */
-/* opt-in hipEvent profiler around the conv kernels (kinds: 0/1 LDS-DMA igemm fwd/dgrad, 2 LDS-DMA wgrad,
- * 3/4 register-staged igemm fwd/dgrad, 5 register-staged wgrad);
+/* opt-in hipEvent profiler around the conv kernels (kinds: 0/1 LDS-DMA igemm fwd/dgrad, 2 LDS-DMA (gather) wgrad,
+ * 3/4 register-staged igemm fwd/dgrad, 5 register-staged wgrad, 6/7 shifted-window conv fwd/dgrad, 8 sliding-window
+ * wgrad);
  * collect sums elapsed ms / algorithmic FLOPs / launches into HOST variables (kind -1: all). */
 int mpr_prof_enable(int on);
 int mpr_prof_reset(void);
@@ -57,45 +62,6 @@ int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S, int 
 int mpr_conv_set_stat_slices(int n);
 /* one-shot: the slice rows given to the NEXT mpr_conv_fwd are already zero (skip its memset) */
 int mpr_conv_stats_prezeroed(int on);
-/* 3x3 / stride 1 / pad 1 convolutions with source channels % 64 == 0 (forward and data gradient) run on the
- * shifted-window kernel (conv_win.hip: the haloed activation window is loaded once per 64-channel block and all nine
- * taps read it at shifted LDS rows); 0 switches it off (tests / comparisons); returns the previous setting */
-int mpr_conv_set_window(int on);
-/* tile / weight-ring variant of the shifted-window kernel (tuning knob, see conv_win.hip; default 5) */
-int mpr_conv_set_window_variant(int v);
-/* rows (B*P*Q) from which the LDS-DMA ring kernel replaces the register-staged one (default 16384);
- * returns the previous threshold */
-int mpr_conv_set_dma_min_rows(int rows);
-/* tile / ring-depth variant of the LDS-DMA kernel (tuning knob, see conv_igemm.hip; default 0, 0) */
-int mpr_conv_set_variant(int narrow, int wide);
-/* stride-2 data gradient: regroup rows into the 4 (h mod 2, w mod 2) classes so a tile walks only the taps that
- * reach it (default 1 = on; 0 = issue every tap with zero-filled holes); returns the previous setting */
-int mpr_conv_set_dgrad_parity(int on);
-/* timing experiments only (results become wrong): bit 0 drops every load of the activation operand of the LDS-DMA
- * conv kernel, bit 1 of the weight operand (zero-record buffer descriptors); returns the previous mask */
-int mpr_conv_debug_drop_operand(int mask);
-/* timing experiments only: the LDS-DMA conv kernel writes 4 time stamps (s_memrealtime, 100 MHz: start, prologue
- * done, main loop done, end) per workgroup into buf[4 * workgroups] (uint64, device memory); NULL switches it off */
-int mpr_conv_debug_stamps(void* buf);
-/* timing experiments only: the shifted-window kernel writes, per workgroup, wave 0's shader-clock sums {total,
- * waiting for DMA, waiting at the barrier, computing, epilogue, end time (100 MHz), -, -} into buf[8 * workgroups] */
-int mpr_conv_debug_probe(void* buf);
-/* timing experiments only: as mpr_conv_debug_stamps, for the LDS-DMA weight-gradient kernel */
-int mpr_conv_debug_wgrad_stamps(void* buf);
-/* timing experiments only: the sliding-window weight-gradient kernel writes wave 0's shader-clock sums {main loop,
- * waiting for DMA, barrier, issuing DMA, computing, chunks, -, -} per workgroup into buf[8 * workgroups] */
-int mpr_conv_debug_wgrad_probe(void* buf);
-/* output pixels (B*P*Q) from which the LDS-DMA weight-gradient kernel is used (default 16384) */
-int mpr_conv_set_wgrad_dma_min_pixels(int pixels);
-/* workgroups the split over pixels of the LDS-DMA weight-gradient kernel aims at (default 512 = one full round of
- * 2 per CU); returns the previous value */
-int mpr_conv_set_wgrad_target_wgs(int n);
-/* output tile of the LDS-DMA weight-gradient kernel on big one-tap GEMMs (transformer linears): 0 = 128 x 128 (4 waves),
- * 1 = 256 x 256 (16 waves), 2 = 256 x 128, 3 = 128 x 256 (8 waves); returns the previous value */
-int mpr_conv_set_wgrad_tile(int v);
-/* weight gradients of 3x3 / stride 1 / pad 1 convolutions (C, K multiples of 64) run on the sliding-window kernel
- * (conv_wgrad_win.hip); 0 switches it off (tests / comparisons); returns the previous setting */
-int mpr_conv_set_wgrad_window(int on);
 /* lend `floats` floats of device scratch to the NEXT mpr_conv_wgrad call (one-shot): the sliding-window kernel then
  * writes each pixel split's partial tile with plain stores and sums the slices in a second kernel on the same stream,
  * instead of fp32 atomics (75 MB per launch at the chip's ~1.3 TB/s atomic rate); too small / NULL: atomics */

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get('MPR_HIP_LIB') or os.path.join(_HERE, 'libmpr_hip.so')     # (override: A/B of two builds)
 HEADER_PATH = os.path.join(_ROOT, 'include', 'mpr_hip.h')
+DEBUG_HEADER_PATH = os.path.join(_ROOT, 'include', 'mpr_hip_debug.h')      # tuning knobs / timing hooks (not the boundary)
 
 
 class NativeLibraryError(RuntimeError):
@@ -61,6 +62,7 @@ def lib():
                 f'(or `make -C multimodal_plankton_recognition_amd/csrc`). There is no CPU fallback.')
         handle = ctypes.CDLL(LIB_PATH)
         _protos = parse_header()
+        _protos.update(parse_header(DEBUG_HEADER_PATH))
         for name, (restype, argtypes) in _protos.items():
             try:
                 fn = getattr(handle, name)

@@ -950,7 +950,7 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
               "mpr_conv_fwd: tensor exceeds 2^31 elements");
   if (mpr_win_eligible((long long)B * P * Q, H, W, C, K, R, S, sh, sw, ph, pw, g_dma_min_rows)) {
     // 3x3 / stride 1 / pad 1: shifted-window kernel (conv_win.hip)
-    void* tok = mpr_prof_begin(0, 2.0 * (double)B * P * Q * K * 9.0 * C, (hipStream_t)stream);
+    void* tok = mpr_prof_begin(6, 2.0 * (double)B * P * Q * K * 9.0 * C, (hipStream_t)stream);      // kind 6: window fwd
     mpr_prof_bytes(tok, 2.0 * ((double)B * H * W * C + 9.0 * C * K + (double)B * P * Q * K));
     g_stats_prezeroed = prezeroed;
     const int rc = mpr_win_launch(false, x, w_fwd, y, nullptr, stats, B, H, W, C, K, (hipStream_t)stream, nullptr);
@@ -980,7 +980,7 @@ int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* ad
   MPR_REQUIRE((long long)B * H * W * C < (1ll << 31) && (long long)B * P * Q * K < (1ll << 31),
               "mpr_conv_dgrad: tensor exceeds 2^31 elements");
   if (mpr_win_eligible((long long)B * H * W, H, W, K, C, R, S, sh, sw, ph, pw, g_dma_min_rows)) {
-    void* tok = mpr_prof_begin(1, 2.0 * (double)B * H * W * C * 9.0 * K, (hipStream_t)stream);
+    void* tok = mpr_prof_begin(7, 2.0 * (double)B * H * W * C * 9.0 * K, (hipStream_t)stream);      // kind 7: window dgrad
     mpr_prof_bytes(tok, 2.0 * ((double)B * P * Q * K + 9.0 * C * K + (double)B * H * W * C * (add ? 2 : 1)));
     const int rc = mpr_win_launch(true, dy, w_dgrad, dx, add, nullptr, B, H, W, K, C, (hipStream_t)stream, nullptr);
     mpr_prof_end(tok, (hipStream_t)stream);
@@ -1016,7 +1016,7 @@ int mpr_conv_dgrad_bn(const void* dy, const void* w_dgrad, void* dz, const void*
               "mpr_conv_dgrad_bn: geometry not served (3x3 / stride 1 / pad 1, K %% 64 == 0, enough rows)");
   MPR_REQUIRE((long long)B * H * W * C < (1ll << 31), "mpr_conv_dgrad_bn: tensor exceeds 2^31 elements");
   WinBnb bnb = {mask_mode, mask_y, bn_x, mean, invstd, scale, shift, slices, nslices, prezeroed};
-  void* tok = mpr_prof_begin(1, 2.0 * (double)B * H * W * C * 9.0 * K, (hipStream_t)stream);
+  void* tok = mpr_prof_begin(7, 2.0 * (double)B * H * W * C * 9.0 * K, (hipStream_t)stream);
   mpr_prof_bytes(tok, 2.0 * ((double)B * H * W * K + 9.0 * C * K + (double)B * H * W * C * (add ? 3 : 2) +
                              (mask_mode == 1 ? (double)B * H * W * C : 0.0)));
   const int rc = mpr_win_launch(true, dy, w_dgrad, dz, add, nullptr, B, H, W, K, C, (hipStream_t)stream, &bnb);

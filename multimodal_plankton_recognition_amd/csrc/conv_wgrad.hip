@@ -494,8 +494,8 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   if (dw_oihw || !accumulate) MPR_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)K * p.Ng, st));
 
   if (mpr_wgw_eligible(p.Mpix, H, W, C, K, R, S, sh, sw, ph, pw, g_wgrad_dma_min_pix)) {
-    // 3x3 / stride 1 / pad 1: sliding-window kernel (conv_wgrad_win.hip)
-    void* tok = mpr_prof_begin(2, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
+    // 3x3 / stride 1 / pad 1: sliding-window kernel (conv_wgrad_win.hip); profiler kind 8
+    void* tok = mpr_prof_begin(8, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
     mpr_prof_bytes(tok, (double)p.x_bytes + (double)p.dy_bytes + 4.0 * K * p.Ng);
     const int rc = mpr_wgw_launch(x, dy, workspace, B, H, W, C, K, g_wgrad_target_wgs, scratch, scratch_floats, st);
     mpr_prof_end(tok, st);

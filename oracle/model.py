@@ -30,8 +30,10 @@ class _View(dict):
         super().__init__({k[len(prefix):]: v for k, v in parent.items() if k.startswith(prefix)})
 
 
-def encode(sd, batch, cfg, train=False):
-    """MultiModel.encode, model.py:72-85."""
+def encode(sd, batch, cfg, train=False, apply_dropout=False):
+    """MultiModel.encode, model.py:72-85.  apply_dropout: also run the encoders' output dropout (image_encoder.py:29,
+    profile_encoder.py:240) in train mode -- off by default because parity runs use p = 0 (RNG streams cannot match);
+    the timed CPU baseline switches it on so that it does the work of the benchmarked step."""
     ie, pe = cfg['image_encoder_args'], cfg['profile_encoder_args']
     img_feat = image_encoder_forward(sub(sd, 'image_encoder.'), batch['image'], batch['image_shape'],
                                      arch=ie['name'], train=train, metadata=ie.get('metadata', True),
@@ -47,6 +49,9 @@ def encode(sd, batch, cfg, train=False):
     else:
         prof_feat = profile_lstm_forward(p, batch['profile'], batch['last_idx'], batch['profile_len'],
                                          pe['num_layers'], pe.get('metadata', True))
+    if apply_dropout and train:
+        img_feat = F.dropout(img_feat, ie.get('dropout', 0.1), True)
+        prof_feat = F.dropout(prof_feat, pe.get('dropout', 0.1), True)
     return {'image_emb': F.linear(img_feat, sd['image_projection.weight']),       # model.py:80
             'profile_emb': F.linear(prof_feat, sd['profile_projection.weight'])}  # model.py:82
 
@@ -87,13 +92,13 @@ def sgd_update(params, grads, bufs, lr, momentum=0.0, weight_decay=0.0, nesterov
             p.add_(g, alpha=-lr)
 
 
-def train_step(sd, batch, cfg, bufs):
+def train_step(sd, batch, cfg, bufs, apply_dropout=False):
     """training_step (model.py:93-101) + backward + SGD step.  Mutates ``sd``/``bufs``; returns
     (loss, grads)."""
     params = {k: v for k, v in sd.items() if is_param(k) and v.is_floating_point()}
     for v in params.values():
         v.requires_grad_(True)
-    emb = encode(sd, batch, cfg, train=True)
+    emb = encode(sd, batch, cfg, train=True, apply_dropout=apply_dropout)
     loss = coordination(sd, emb, cfg, batch.get('buckets', 1))
     grads = dict(zip(params, torch.autograd.grad(loss, list(params.values()), allow_unused=True)))
     for v in params.values():

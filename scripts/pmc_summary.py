@@ -35,15 +35,32 @@ for k, a in agg.items():
               'hbm_bytes_per_launch': (rd + wr) / a['launches']}
 
 
-def family(*prefixes):
-    ks = [k for k in out if k.startswith(prefixes)]
+def family(pred):
+    ks = [k for k in out if pred(k)]
     n = sum(out[k]['launches_per_step'] for k in ks)
     b = sum(out[k]['read_bytes_per_step'] + out[k]['write_bytes_per_step'] for k in ks)
-    return {'launches_per_step': n, 'hbm_bytes_per_launch': b / max(n, 1), 'hbm_bytes_per_step': b}
+    return {'launches_per_step': n, 'hbm_bytes_per_launch': b / max(n, 1), 'hbm_bytes_per_step': b, 'kernels': ks}
 
 
+def win(k, dgrad):
+    """conv_win_kernel<WM, WN, TM, TN, STAGES, DGRAD, ...> / conv_win_persist_kernel<DGRAD>"""
+    m = re.match(r'conv_win_kernel<([^>]*)>', k)
+    if m:
+        return m.group(1).split(',')[5].strip() == ('true' if dgrad else 'false')
+    m = re.match(r'conv_win_persist_kernel<([^>]*)>', k)
+    return bool(m) and m.group(1).strip() == ('true' if dgrad else 'false')
+
+
+families = {'win_fwd': family(lambda k: win(k, False)), 'win_dgrad': family(lambda k: win(k, True)),
+            'win_fwd_dgrad': family(lambda k: win(k, False) or win(k, True)),
+            'dma_fwd_dgrad': family(lambda k: k.startswith('conv_igemm_dma_kernel')),
+            'wgrad_win': family(lambda k: k.startswith('conv_wgrad_win_kernel')),
+            'wgrad_dma': family(lambda k: k.startswith('conv_wgrad_dma_kernel')),
+            'batchnorm_pool': family(lambda k: k.startswith(('bn_', '_Z', 'pool_', 'global_')) or 'bn_' in k),
+            'stem_fused': family(lambda k: k.startswith('stemf_'))}
 summary = {'tag': tag, 'workload': (sys.argv[2] if len(sys.argv) > 2 else 'bench.py C3 step, batch 512, one MI355X'), 'correction': 'read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB',
-           'conv_igemm_dma_kernel': family('conv_igemm_dma_kernel', 'conv_win_kernel'), 'conv_wgrad_dma_kernel': family('conv_wgrad_dma_kernel'),
+           'families': families,
+           'launches_per_step': sum(v['launches_per_step'] for v in out.values()),
            'whole_step_hbm_bytes': sum(v['read_bytes_per_step'] + v['write_bytes_per_step'] for v in out.values()),
            'kernels': out}
 json.dump(summary, open(f'profiles/{tag}_pmc_traffic.json', 'w'), indent=1)
@@ -54,5 +71,8 @@ with open(f'profiles/{tag}_pmc_traffic.md', 'w') as f:
     for k, v in sorted(out.items(), key=lambda kv: -(kv[1]['read_bytes_per_step'] + kv[1]['write_bytes_per_step'])):
         f.write(f"| {k} | {v['launches_per_step']} | {v['read_bytes_per_step']/1e6:.1f} | {v['write_bytes_per_step']/1e6:.1f} | "
                 f"{v['hbm_bytes_per_launch']/1e6:.2f} |\n")
-    f.write(f"\nwhole step: {summary['whole_step_hbm_bytes']/1e9:.2f} GB\n")
+    f.write(f"\nwhole step: {summary['whole_step_hbm_bytes']/1e9:.2f} GB in {summary['launches_per_step']} launches\n\n")
+    f.write('| family | launches/step | MB/launch | GB/step |\n|---|---|---|---|\n')
+    for k, v in families.items():
+        f.write(f"| {k} | {v['launches_per_step']} | {v['hbm_bytes_per_launch']/1e6:.1f} | {v['hbm_bytes_per_step']/1e9:.2f} |\n")
 print(open(f'profiles/{tag}_pmc_traffic.md').read())

@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage: scripts/prof_round.sh <round tag, e.g. r02>   (on the GPU box via gpurun; ~8 minutes)
+# Everything the judged numbers come from, for one build: the default bench line, a kernel trace of three steps (+ the
+# per-kernel summary of one step), HBM traffic per kernel (two PMC passes), MFMA utilisation (one PMC pass).
+# Summaries land in gpurun_out/ and are copied to profiles/ by hand (they are the committed evidence).
+export TMPDIR=/tmp
+t=$1
+mkdir -p gpurun_out profiles
+python bench.py > gpurun_out/bench_$t.log 2>&1; tail -1 gpurun_out/bench_$t.log > gpurun_out/${t}_bench_line.json; cut -c1-200 gpurun_out/${t}_bench_line.json
+bash scripts/prof_step.sh $t 2>&1 | tail -1
+python3 scripts/prof_summary.py $t 60 > gpurun_out/${t}_step_kernel_summary.txt 2>&1; head -2 gpurun_out/${t}_step_kernel_summary.txt
+cp gpurun_out/prof_$t/*/*kernel_stats.csv gpurun_out/${t}_bench_kernel_stats.csv 2>/dev/null
+bash scripts/prof_pmc.sh $t > gpurun_out/pmc_$t.log 2>&1
+python3 scripts/pmc_summary.py $t > gpurun_out/pmc_${t}_summary.log 2>&1; tail -12 gpurun_out/pmc_${t}_summary.log
+cp profiles/${t}_pmc_traffic.* gpurun_out/ 2>/dev/null
+bash scripts/prof_mfma.sh ${t}_c3 > gpurun_out/mfma_${t}_sum.log 2>&1
+cp profiles/${t}_c3_mfma_util.* gpurun_out/ 2>/dev/null; tail -4 gpurun_out/mfma_${t}_sum.log | cut -c1-200

@@ -1,5 +1,6 @@
-"""CPU: the C-ABI library builds/loads and exports every symbol include/mpr_hip.h declares; calling a
-kernel wrapper with CPU tensors fails loudly (there is no CPU fallback)."""
+"""CPU: the C-ABI library builds/loads and exports every symbol include/mpr_hip.h (the boundary) and
+include/mpr_hip_debug.h (tuning knobs / timing hooks) declare; calling a kernel wrapper with CPU tensors fails loudly
+(there is no CPU fallback)."""
 import os
 import re
 
@@ -12,9 +13,15 @@ from multimodal_plankton_recognition_amd import _native
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(_native.LIB_PATH), 'run __graft_entry__.build() first'
     names = _native.exported_symbols()
-    text = open(_native.HEADER_PATH).read()
-    declared = set(re.findall(r'\b(mpr_\w+)\s*\(', re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)))
-    assert declared and declared == set(names)
+    decl = {}
+    for path in (_native.HEADER_PATH, _native.DEBUG_HEADER_PATH):
+        text = open(path).read()
+        decl[path] = set(re.findall(r'\b(mpr_\w+)\s*\(', re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)))
+    boundary, debug = decl[_native.HEADER_PATH], decl[_native.DEBUG_HEADER_PATH]
+    assert boundary and debug and not (boundary & debug)
+    assert boundary | debug == set(names)
+    # nothing that makes results wrong, and no kernel-variant switch, is part of the drop-in boundary
+    assert not any(n.startswith('mpr_conv_debug_') or 'variant' in n for n in boundary)
     assert _native.query('mpr_abi_version') == 1
     assert _native.lib().mpr_target_arch() == b'gfx950'
 
