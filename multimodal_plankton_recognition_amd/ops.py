@@ -242,7 +242,15 @@ def conv_dgrad(dy, wd, g, x_shape, add=None):
 
 AUTOTUNE = os.environ.get('MPR_AUTOTUNE', '1') != '0'
 _FIXED_WGRAD_WGS = int(os.environ.get('MPR_WGRAD_WGS', '0'))      # experiments: one target for every geometry
-_wgrad_split = {}          # geometry -> workgroup-count target of the split over pixels
+_wgrad_split = {}          # geometry -> (window kernel?, workgroup-count target of the split over pixels)
+# MPR_WGRAD_PLAN=<file>: the tuner's choices are loaded from / appended to this JSON file, so that a run whose timings
+# cannot be trusted (rocprofv3 --pmc serialises kernels and the tuner then prefers other kernels than the real step
+# runs) executes the plan of an undisturbed run: scripts/prof_pmc.sh, scripts/prof_mfma.sh
+_WGRAD_PLAN = os.environ.get('MPR_WGRAD_PLAN')
+if _WGRAD_PLAN and os.path.exists(_WGRAD_PLAN):
+    import json as _json
+    with open(_WGRAD_PLAN) as _f:
+        _wgrad_split.update({tuple(int(v) for v in k.split(',')): tuple(c) for k, c in _json.load(_f).items()})
 
 
 WGRAD_SCRATCH_FLOATS = 20 * 1024 * 1024      # 80 MB per stream: 256 workgroups x 128 x 576 accumulators (+ margin)
@@ -290,6 +298,10 @@ def _tune_wgrad(x, dy, g, key):
             best, best_t = (win, tg), t
     N.query('mpr_conv_set_wgrad_window', old_win)
     _wgrad_split[key] = best
+    if _WGRAD_PLAN:
+        import json
+        with open(_WGRAD_PLAN, 'w') as f:
+            json.dump({','.join(str(int(v)) for v in k): list(c) for k, c in _wgrad_split.items()}, f, indent=0)
     return best
 
 

@@ -6,6 +6,9 @@
 export TMPDIR=/tmp
 t=$1
 mkdir -p gpurun_out profiles
+# the weight-gradient tuner's choices of the undisturbed bench run are replayed by the profiled runs (ops.py MPR_WGRAD_PLAN)
+rm -f gpurun_out/${t}_wgrad_plan.json
+export MPR_WGRAD_PLAN=gpurun_out/${t}_wgrad_plan.json
 python bench.py > gpurun_out/bench_$t.log 2>&1; tail -1 gpurun_out/bench_$t.log > gpurun_out/${t}_bench_line.json; cut -c1-200 gpurun_out/${t}_bench_line.json
 bash scripts/prof_step.sh $t 2>&1 | tail -1
 python3 scripts/prof_summary.py $t 60 > gpurun_out/${t}_step_kernel_summary.txt 2>&1; head -2 gpurun_out/${t}_step_kernel_summary.txt
