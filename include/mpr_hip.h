@@ -310,6 +310,22 @@ int mpr_siglip_bwd(float* S, const float* logit_scale, const float* bias, const 
                    float* d_bias, float* workspace, int buckets, int n, void* stream);
 int mpr_mse_add(const float* a, const float* b, float beta, float* loss, float* workspace, long long total,
                 void* stream);
+/* CLIP / SigLIP without the similarity matrix in memory (csrc/loss_fused.hip; replaces src/coordination.py:33-47 and
+ * :81-95 -- normalise, all-pairs logits, both softmax axes, their gradients -- for one process AND for the data-parallel
+ * row block).  gathered: normalised embeddings of every rank [world][2][b][D] (world == 1: [2][buckets * b][D], the
+ * output of mpr_clipf_norm); bias == NULL selects CLIP.  Shapes and the meaning of lse / out / coef: loss_fused.hip. */
+long long mpr_clipf_workspace_floats(int world, int b, int D, int buckets);
+int mpr_clipf_norm(const float* image_emb, const float* profile_emb, float* uv /* [2][rows][D] */,
+                   float* inv_norm /* [2][rows] */, int rows, int D, void* stream);
+int mpr_clipf_fwd(const float* gathered, const float* logit_scale, const float* bias /* NULL: CLIP */,
+                  float* lse /* [2][buckets * b]; SigLIP: may be NULL */, float* out /* [1] */, float mul, float* workspace,
+                  int world, int rank, int b, int D, int buckets, void* stream);
+int mpr_clipf_bwd(const float* gathered, const float* logit_scale, const float* bias, const float* lse_own,
+                  const float* lse_other /* [world][2][b] */, float coef, const float* uv, const float* inv_norm,
+                  const float* image_emb /* may be NULL */, const float* profile_emb, float mse_coef,
+                  const float* gout /* [1] or NULL */, float* d_image, float* d_profile,
+                  float* d_logit_scale /* may be NULL */, float* d_bias /* may be NULL */, float* workspace, int world,
+                  int rank, int b, int D, int buckets, void* stream);
 /* RankLoss (src/coordination.py:115-135) on the raw cosine matrix S [n][n] (diagonal negated on the fly):
  * row / column sums, loss = (mean relu(margin + colsum) + mean relu(margin + rowsum)) / 2, and dL/dS */
 int mpr_rank_fwd(const float* S, float margin, float* row_sum, float* col_sum, float* loss, int n, void* stream);

@@ -38,7 +38,7 @@ def parse_header(path=HEADER_PATH):
     protos = {}
     for m in re.finditer(r'(?:^|\n)\s*((?:const\s+)?\w[\w\s]*?\*?)\s*(mpr_\w+)\s*\(([^;{]*?)\)\s*;', text):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if '*' in ret else (None if ret == 'void' else ctypes.c_int)
+        restype = ctypes.c_char_p if '*' in ret else (None if ret == 'void' else ctypes.c_longlong if ret == 'long long' else ctypes.c_int)
         if args in ('void', ''):
             argtypes = []
         elif '...' in args:

@@ -1,6 +1,7 @@
 """Cross-modal coordination losses -- drop-in counterparts of /root/reference/src/coordination.py
 (same class names, parameters, ``forward(image_emb, profile_emb, buckets=1)`` contract and
-``state_dict`` keys), computed end-to-end in fp32 by the kernels of csrc/loss.hip + gemm_f32.hip.
+``state_dict`` keys), computed end-to-end in fp32: CLIP / SigLIP (+ MSE) by csrc/loss_fused.hip (no B x B matrix in
+memory), RankLoss and the retrieval arg-max by csrc/loss.hip + gemm_f32.hip on the materialised cosine matrix.
 """
 import torch
 from torch import Tensor, nn
@@ -45,62 +46,53 @@ def _embedding_grads(ctx, S_grad, gout, a, p, u, v, iu, iv, n, buckets, beta):
     return da, dp
 
 
-class _ClipFn(torch.autograd.Function):
-    """src/coordination.py:26-47 (+ beta * MSE of :60-64 when beta != 0)."""
-
-    @staticmethod
-    def forward(ctx, image_emb, profile_emb, logit_scale, buckets, beta):
-        a, p, u, v, iu, iv, S, n = _prep(image_emb, profile_emb, buckets)
-        dev = a.device
-        rows = a.shape[0]
-        row_lse = torch.empty(rows, dtype=F32, device=dev)
-        col_lse = torch.empty(rows, dtype=F32, device=dev)
-        diag = torch.empty(rows, dtype=F32, device=dev)
-        loss = torch.empty((), dtype=F32, device=dev)
-        N.call('mpr_clip_fwd', S, logit_scale.detach(), row_lse, col_lse, diag, loss, buckets, n)
-        if beta:
-            N.call('mpr_mse_add', a, p, float(beta), loss, _workspace(dev), a.numel())
-        ctx.save_for_backward(a, p, u, v, iu, iv, S, row_lse, col_lse, logit_scale)
-        ctx.cfg = (n, buckets, beta)
-        return loss
-
-    @staticmethod
-    def backward(ctx, gout):
-        a, p, u, v, iu, iv, S, row_lse, col_lse, logit_scale = ctx.saved_tensors
-        n, buckets, beta = ctx.cfg
-        gout = gout.contiguous().float()
-        dls = torch.empty((), dtype=F32, device=a.device)
-        G = S.clone()       # keep the saved logits intact (backward may be re-run)
-        N.call('mpr_clip_bwd', G, logit_scale.detach(), row_lse, col_lse, gout, dls, _workspace(a.device), buckets, n)
-        da, dp = _embedding_grads(ctx, G, gout, a, p, u, v, iu, iv, n, buckets, beta)
-        return da, dp, dls, None, None
-
-
-class _SigLipFn(torch.autograd.Function):
-    """src/coordination.py:76-95 (+ beta * MSE of :108-112 when beta != 0)."""
+class _PairLossFn(torch.autograd.Function):
+    """CLIP (src/coordination.py:26-47) and SigLIP (:76-95), + beta * MSE (:60-64, :108-112) when beta != 0, on the
+    kernels of csrc/loss_fused.hip: normalise -> similarity tiles on the fp32 MFMA, consumed in place (row log-sum-exps /
+    -logsigmoid sums) -> the same tiles formed again in backward for G Y.  The B x B matrix is never stored; `buckets`
+    are independent problems over consecutive row blocks.  bias is None: CLIP."""
 
     @staticmethod
     def forward(ctx, image_emb, profile_emb, logit_scale, bias, buckets, beta):
-        a, p, u, v, iu, iv, S, n = _prep(image_emb, profile_emb, buckets)
+        assert image_emb.size(0) % buckets == 0, "Batch size must be divisible by number of buckets!"
+        a = image_emb.contiguous().float()
+        p = profile_emb.contiguous().float()
+        rows, D = a.shape
+        b = rows // buckets
         dev = a.device
+        uv = torch.empty(2, rows, D, dtype=F32, device=dev)
+        inv = torch.empty(2, rows, dtype=F32, device=dev)
+        N.call('mpr_clipf_norm', a, p, uv, inv, rows, D)
+        ws = torch.empty(N.query('mpr_clipf_workspace_floats', 1, b, D, buckets), dtype=F32, device=dev)
         loss = torch.empty((), dtype=F32, device=dev)
-        N.call('mpr_siglip_fwd', S, logit_scale.detach(), bias.detach(), loss, _workspace(dev), buckets, n)
+        ls = logit_scale.detach()
+        if bias is None:
+            lse = torch.empty(2, rows, dtype=F32, device=dev)
+            N.call('mpr_clipf_fwd', uv, ls, None, lse, loss, 1.0 / (2.0 * rows), ws, 1, 0, b, D, buckets)
+        else:
+            lse = None
+            N.call('mpr_clipf_fwd', uv, ls, bias.detach(), None, loss, 1.0 / rows, ws, 1, 0, b, D, buckets)
         if beta:
             N.call('mpr_mse_add', a, p, float(beta), loss, _workspace(dev), a.numel())
-        ctx.save_for_backward(a, p, u, v, iu, iv, S, logit_scale, bias)
-        ctx.cfg = (n, buckets, beta)
+        ctx.save_for_backward(a, p, uv, inv, lse, logit_scale, bias)
+        ctx.cfg = (b, buckets, beta)
         return loss
 
     @staticmethod
     def backward(ctx, gout):
-        a, p, u, v, iu, iv, S, logit_scale, bias = ctx.saved_tensors
-        n, buckets, beta = ctx.cfg
+        a, p, uv, inv, lse, logit_scale, bias = ctx.saved_tensors
+        b, buckets, beta = ctx.cfg
+        rows, D = a.shape
+        dev = a.device
         gout = gout.contiguous().float()
-        dls = torch.empty((), dtype=F32, device=a.device)
-        db = torch.empty((), dtype=F32, device=a.device)
-        G = S.clone()
-        N.call('mpr_siglip_bwd', G, logit_scale.detach(), bias.detach(), gout, dls, db, _workspace(a.device), buckets, n)
-        da, dp = _embedding_grads(ctx, G, gout, a, p, u, v, iu, iv, n, buckets, beta)
+        da, dp = torch.empty_like(a), torch.empty_like(p)
+        dls = torch.empty((), dtype=F32, device=dev)
+        db = torch.empty((), dtype=F32, device=dev) if bias is not None else None
+        ws = torch.empty(N.query('mpr_clipf_workspace_floats', 1, b, D, buckets), dtype=F32, device=dev)
+        coef = 1.0 / (2.0 * rows) if bias is None else 1.0 / rows
+        N.call('mpr_clipf_bwd', uv, logit_scale.detach(), None if bias is None else bias.detach(), lse, lse, coef, uv, inv,
+               a if beta else None, p if beta else None, 2.0 * beta / a.numel() if beta else 0.0, gout, da, dp, dls, db,
+               ws, 1, 0, b, D, buckets)
         return da, dp, dls, db, None, None
 
 
@@ -122,7 +114,7 @@ class CLIPLoss(nn.Module):
         self.logit_scale = Parameter(torch.ones([]))
 
     def forward(self, image_emb: Tensor, profile_emb: Tensor, buckets: int = 1) -> Tensor:
-        return _ClipFn.apply(image_emb, profile_emb, self.logit_scale, int(buckets), 0.0)
+        return _PairLossFn.apply(image_emb, profile_emb, self.logit_scale, None, int(buckets), 0.0)
 
 
 class CLIPPlus(nn.Module):
@@ -134,7 +126,7 @@ class CLIPPlus(nn.Module):
         self.beta = beta
 
     def forward(self, image_emb: Tensor, profile_emb: Tensor, buckets: int = 1) -> Tensor:
-        return _ClipFn.apply(image_emb, profile_emb, self.clip.logit_scale, int(buckets), float(self.beta))
+        return _PairLossFn.apply(image_emb, profile_emb, self.clip.logit_scale, None, int(buckets), float(self.beta))
 
 
 class SigLIPLoss(nn.Module):
@@ -146,7 +138,7 @@ class SigLIPLoss(nn.Module):
         self.bias = Parameter(-10 * torch.ones([]))
 
     def forward(self, image_emb: Tensor, profile_emb: Tensor, buckets: int = 1) -> Tensor:
-        return _SigLipFn.apply(image_emb, profile_emb, self.logit_scale, self.bias, int(buckets), 0.0)
+        return _PairLossFn.apply(image_emb, profile_emb, self.logit_scale, self.bias, int(buckets), 0.0)
 
 
 class SigLIPPlus(nn.Module):
@@ -158,8 +150,8 @@ class SigLIPPlus(nn.Module):
         self.beta = beta
 
     def forward(self, image_emb: Tensor, profile_emb: Tensor, buckets: int = 1) -> Tensor:
-        return _SigLipFn.apply(image_emb, profile_emb, self.siglip.logit_scale, self.siglip.bias, int(buckets),
-                               float(self.beta))
+        return _PairLossFn.apply(image_emb, profile_emb, self.siglip.logit_scale, self.siglip.bias, int(buckets),
+                                  float(self.beta))
 
 
 class _RankFn(torch.autograd.Function):

@@ -5,8 +5,8 @@ for.  Samples are sharded over ranks (rank r owns rows [r*b, (r+1)*b) of the glo
 and BatchNorm statistics are per rank, and the ONLY coupling is the global contrastive matrix:
 
   1. all-gather of the L2-normalised embeddings  (2 x [b, D] fp32 per rank, one collective)
-  2. every rank forms only ITS row blocks  U_loc V_all^T  and  V_loc U_all^T  ([b, n] each, never the
-     n x n matrix), whose row log-sum-exps are local
+  2. every rank walks only ITS row blocks  U_loc V_all^T  and  V_loc U_all^T  (b x n each, tile by tile on the fp32
+     MFMA -- neither the n x n matrix nor the blocks are stored: csrc/loss_fused.hip), whose row log-sum-exps are local
   3. all-gather of the two LSE vectors (2 x [b] fp32) -- the softmax over the other axis needs them
   4. dL/dU_loc, dL/dV_loc are then computed locally against U_all / V_all (no reduce-scatter of
      embedding gradients); the loss value and d(logit_scale) are summed over ranks
@@ -106,73 +106,76 @@ class Comm:
 
 # ------------------------------------------------------------------------------------------------ math back end
 class HipClipMath:
-    """The per-rank arithmetic of the sharded CLIP loss on the gfx950 kernels (no fallback)."""
+    """The per-rank arithmetic of the sharded CLIP / SigLIP loss on the gfx950 kernels of csrc/loss_fused.hip (no
+    fallback): the row blocks  U_loc V_all^T  and  V_loc U_all^T  are formed tile by tile on the fp32 MFMA and never stored.
+    `gathered` is the all-gathered [world, 2, b, D] tensor of normalised embeddings (image, profile per rank)."""
 
-    def normalize(self, x):
-        x = x.detach().contiguous().float()
-        u = torch.empty_like(x)
-        inv = torch.empty(x.shape[0], dtype=F32, device=x.device)
-        N.call('mpr_l2norm_fwd', x, u, inv, x.shape[0], x.shape[1])
-        return u, inv
+    def _ws(self, gathered):
+        world, _, b, D = gathered.shape
+        return torch.empty(N.query('mpr_clipf_workspace_floats', world, b, D, 1), dtype=F32, device=gathered.device)
 
-    def logits(self, x_loc, y_all):
-        return ops.gemm(x_loc, y_all, trans_b=True)
+    def normalize(self, image_emb, profile_emb):
+        """-> uv [2, b, D] (F.normalize of both modalities), inv [2, b] (1 / max(|x|, 1e-12))."""
+        b, D = image_emb.shape
+        uv = torch.empty(2, b, D, dtype=F32, device=image_emb.device)
+        inv = torch.empty(2, b, dtype=F32, device=image_emb.device)
+        N.call('mpr_clipf_norm', image_emb, profile_emb, uv, inv, b, D)
+        return uv, inv
 
-    def _ws(self, dev):
-        return torch.empty(N.query('mpr_loss_workspace_floats'), dtype=F32, device=dev)
+    def clip_fwd(self, gathered, logit_scale, rank, mul):
+        """-> lse [2, b] (row log-sum-exps of my image rows / my profile rows), mul * sum (lse - positive logit)."""
+        world, _, b, D = gathered.shape
+        lse = torch.empty(2, b, dtype=F32, device=gathered.device)
+        share = torch.empty((), dtype=F32, device=gathered.device)
+        N.call('mpr_clipf_fwd', gathered, logit_scale.detach(), None, lse, share, float(mul), self._ws(gathered),
+               world, rank, b, D, 1)
+        return lse, share
 
-    def block_fwd(self, S, logit_scale, off):
-        rows, ncols = S.shape
-        lse = torch.empty(rows, dtype=F32, device=S.device)
-        diag = torch.empty(rows, dtype=F32, device=S.device)
-        total = torch.empty((), dtype=F32, device=S.device)
-        N.call('mpr_clip_block_fwd', S, logit_scale.detach(), lse, diag, total, self._ws(S.device), rows, ncols, off)
-        return lse, total
+    def clip_bwd(self, gathered, logit_scale, lse, lse_all, rank, coef, uv, inv, image_emb=None, profile_emb=None,
+                 mse_coef=0.0):
+        """-> dL/d image_emb, dL/d profile_emb [b, D], this rank's share of d logit_scale."""
+        world, _, b, D = gathered.shape
+        dev = gathered.device
+        d_img, d_prof = torch.empty(b, D, dtype=F32, device=dev), torch.empty(b, D, dtype=F32, device=dev)
+        dls = torch.empty((), dtype=F32, device=dev)
+        N.call('mpr_clipf_bwd', gathered, logit_scale.detach(), None, lse, lse_all, float(coef), uv, inv, image_emb,
+               profile_emb, float(mse_coef), None, d_img, d_prof, dls, None, self._ws(gathered), world, rank, b, D, 1)
+        return d_img, d_prof, dls
 
-    def block_bwd(self, S, logit_scale, lse_own, lse_other, off, coef):
-        rows, ncols = S.shape
-        dls = torch.empty((), dtype=F32, device=S.device)
-        N.call('mpr_clip_block_bwd', S, logit_scale.detach(), lse_own, lse_other, None, float(coef), dls,
-               self._ws(S.device), rows, ncols, off)
-        return dls
+    def siglip_fwd(self, gathered, logit_scale, bias, rank, mul):
+        """-> mul * sum over my image rows x all profiles of -logsigmoid(+-z)."""
+        world, _, b, D = gathered.shape
+        share = torch.empty((), dtype=F32, device=gathered.device)
+        N.call('mpr_clipf_fwd', gathered, logit_scale.detach(), bias.detach(), None, share, float(mul),
+               self._ws(gathered), world, rank, b, D, 1)
+        return share
 
-    def matmul(self, g, y_all):
-        return ops.gemm(g, y_all)
-
-    def normalize_bwd(self, du, u, inv, x=None, other=None, mse_coef=0.0):
-        """+ mse_coef * (x - other): the local gradient of the MSE term of the *Plus losses."""
-        dx = torch.empty_like(u)
-        N.call('mpr_l2norm_bwd', du, u, inv, x, other, float(mse_coef), None, dx, u.shape[0], u.shape[1])
-        return dx
-
-    # ---- SigLIP row block
-    def siglip_block_fwd(self, S, logit_scale, bias, off):
-        rows, ncols = S.shape
-        total = torch.empty((), dtype=F32, device=S.device)
-        N.call('mpr_siglip_block_fwd', S, logit_scale.detach(), bias.detach(), total, self._ws(S.device), rows, ncols, off)
-        return total
-
-    def siglip_block_bwd(self, S, logit_scale, bias, off, coef, want_param_grads):
-        rows, ncols = S.shape
-        dls = torch.empty((), dtype=F32, device=S.device) if want_param_grads else None
-        db = torch.empty((), dtype=F32, device=S.device) if want_param_grads else None
-        N.call('mpr_siglip_block_bwd', S, logit_scale.detach(), bias.detach(), float(coef), dls, db, self._ws(S.device),
-               rows, ncols, off)
-        return dls, db
+    def siglip_bwd(self, gathered, logit_scale, bias, rank, coef, uv, inv, image_emb=None, profile_emb=None,
+                   mse_coef=0.0):
+        """-> dL/d image_emb, dL/d profile_emb, this rank's shares of d logit_scale and d bias."""
+        world, _, b, D = gathered.shape
+        dev = gathered.device
+        d_img, d_prof = torch.empty(b, D, dtype=F32, device=dev), torch.empty(b, D, dtype=F32, device=dev)
+        dls, db = torch.empty((), dtype=F32, device=dev), torch.empty((), dtype=F32, device=dev)
+        N.call('mpr_clipf_bwd', gathered, logit_scale.detach(), bias.detach(), None, None, float(coef), uv, inv,
+               image_emb, profile_emb, float(mse_coef), None, d_img, d_prof, dls, db, self._ws(gathered), world, rank,
+               b, D, 1)
+        return d_img, d_prof, dls, db
 
     def sqdiff_sum(self, a, b):
         out = torch.empty((), dtype=F32, device=a.device)
-        N.call('mpr_sqdiff_sum', a.contiguous(), b.contiguous(), out, self._ws(a.device), a.numel())
+        ws = torch.empty(N.query('mpr_loss_workspace_floats'), dtype=F32, device=a.device)
+        N.call('mpr_sqdiff_sum', a.contiguous(), b.contiguous(), out, ws, a.numel())
         return out
 
 
-def _mse_term(image_emb, profile_emb, beta, n, comm, math):
+def _mse_term(a32, p32, beta, n, comm, math):
     """beta * MSELoss(image_emb, profile_emb) over the GLOBAL batch (src/coordination.py:60-64,108-112):
     -> (loss share summed over ranks, coefficient of (x - other) in the local embedding gradients)."""
     if not beta:
         return None, 0.0
-    D = image_emb.shape[1]
-    local = math.sqdiff_sum(image_emb.detach().float(), profile_emb.detach().float())
+    D = a32.shape[1]
+    local = math.sqdiff_sum(a32, p32)
     total = comm.all_reduce_sum(local.reshape(1).clone()).reshape(())
     return total * (float(beta) / (n * D)), 2.0 * float(beta) / (n * D)
 
@@ -181,31 +184,21 @@ def dp_siglip(image_emb, profile_emb, logit_scale, bias, comm, math, beta=0.0):
     """Sharded SigLIP loss (src/coordination.py:76-95 over the GLOBAL batch, buckets = 1; + beta * MSE for SigLIPPlus).
 
     Every (image i, profile j) pair is owned by the rank that owns row i: the loss and the parameter gradients are sums of
-    the row-block shares.  The profile gradients need column j against ALL images, so each rank also forms its column block
-    V_loc U_all^T (the pair function is symmetric in its two roles) -- twice the tiny GEMM instead of a reduce-scatter of
-    [n, D] gradients.  Returns (loss, dL/d image_emb, dL/d profile_emb, d logit_scale share, d bias share)."""
+    the row-block shares.  The profile gradients need column j against ALL images, so each rank also walks its column block
+    V_loc U_all^T (the pair function is symmetric in its two roles) -- twice the tiny product instead of a reduce-scatter
+    of [n, D] gradients.  Returns (loss, dL/d image_emb, dL/d profile_emb, d logit_scale share, d bias share)."""
     b = image_emb.shape[0]
     n = b * comm.world
-    off = comm.rank * b
-    u, iu = math.normalize(image_emb)
-    v, iv = math.normalize(profile_emb)
-    both = comm.all_gather(torch.stack((u, v)))                      # [world, 2, b, D]
-    D = u.shape[1]
-    u_all = both[:, 0].reshape(n, D).contiguous()
-    v_all = both[:, 1].reshape(n, D).contiguous()
-    s_img = math.logits(u, v_all)
-    s_prof = math.logits(v, u_all)
-    share = math.siglip_block_fwd(s_img, logit_scale, bias, off)
-    loss = comm.all_reduce_sum((share / n).reshape(1).clone()).reshape(())
-    mse, mse_coef = _mse_term(image_emb, profile_emb, beta, n, comm, math)
+    a32, p32 = image_emb.detach().float().contiguous(), profile_emb.detach().float().contiguous()
+    uv, inv = math.normalize(a32, p32)
+    gathered = comm.all_gather(uv)                                   # [world, 2, b, D]
+    share = math.siglip_fwd(gathered, logit_scale, bias, comm.rank, 1.0 / n)
+    loss = comm.all_reduce_sum(share.reshape(1).clone()).reshape(())
+    mse, mse_coef = _mse_term(a32, p32, beta, n, comm, math)
     if mse is not None:
         loss = loss + mse
-    coef = 1.0 / n
-    dls, db = math.siglip_block_bwd(s_img, logit_scale, bias, off, coef, True)       # s_img  <- G
-    math.siglip_block_bwd(s_prof, logit_scale, bias, off, coef, False)               # s_prof <- G^T (my columns)
-    a32, p32 = image_emb.detach().float().contiguous(), profile_emb.detach().float().contiguous()
-    d_img = math.normalize_bwd(math.matmul(s_img, v_all), u, iu, a32 if beta else None, p32 if beta else None, mse_coef)
-    d_prof = math.normalize_bwd(math.matmul(s_prof, u_all), v, iv, p32 if beta else None, a32 if beta else None, mse_coef)
+    d_img, d_prof, dls, db = math.siglip_bwd(gathered, logit_scale, bias, comm.rank, 1.0 / n, uv, inv,
+                                             a32 if beta else None, p32 if beta else None, mse_coef)
     return loss, d_img, d_prof, dls, db
 
 
@@ -216,33 +209,19 @@ def dp_clip(image_emb, profile_emb, logit_scale, comm, math, beta=0.0):
     d logit_scale [this rank's partial: the total is the SUM over ranks])."""
     b = image_emb.shape[0]
     n = b * comm.world
-    off = comm.rank * b
-    u, iu = math.normalize(image_emb)
-    v, iv = math.normalize(profile_emb)
-    both = comm.all_gather(torch.stack((u, v)))                      # [world, 2, b, D]
-    D = u.shape[1]
-    u_all = both[:, 0].reshape(n, D).contiguous()
-    v_all = both[:, 1].reshape(n, D).contiguous()
-    s_img = math.logits(u, v_all)                                    # rows: my images,   cols: all profiles
-    s_prof = math.logits(v, u_all)                                   # rows: my profiles, cols: all images
-    lse_r, sum_r = math.block_fwd(s_img, logit_scale, off)
-    lse_c, sum_c = math.block_fwd(s_prof, logit_scale, off)
-    lses = comm.all_gather(torch.stack((lse_r, lse_c)))              # [world, 2, b]
-    lse_r_all = lses[:, 0].reshape(n).contiguous()
-    lse_c_all = lses[:, 1].reshape(n).contiguous()
-    loss = comm.all_reduce_sum(((sum_r + sum_c) / (2.0 * n)).reshape(1).clone()).reshape(())
-    coef = 1.0 / (2.0 * n)
-    dls = math.block_bwd(s_img, logit_scale, lse_r, lse_c_all, off, coef)      # s_img  <- G  * scale
-    math.block_bwd(s_prof, logit_scale, lse_c, lse_r_all, off, coef)           # s_prof <- G^T * scale (my columns)
-    if beta:
-        mse, mse_coef = _mse_term(image_emb, profile_emb, beta, n, comm, math)
+    a32, p32 = image_emb.detach().float().contiguous(), profile_emb.detach().float().contiguous()
+    uv, inv = math.normalize(a32, p32)
+    gathered = comm.all_gather(uv)                                   # [world, 2, b, D]
+    # lse[0]: my images over all profiles, lse[1]: my profiles over all images; the softmax over the other axis of a
+    # row block needs every rank's vector of the other role
+    lse, share = math.clip_fwd(gathered, logit_scale, comm.rank, 1.0 / (2.0 * n))
+    lse_all = comm.all_gather(lse)                                   # [world, 2, b]
+    loss = comm.all_reduce_sum(share.reshape(1).clone()).reshape(())
+    mse, mse_coef = _mse_term(a32, p32, beta, n, comm, math)
+    if mse is not None:
         loss = loss + mse
-        a32, p32 = image_emb.detach().float().contiguous(), profile_emb.detach().float().contiguous()
-        d_img = math.normalize_bwd(math.matmul(s_img, v_all), u, iu, a32, p32, mse_coef)
-        d_prof = math.normalize_bwd(math.matmul(s_prof, u_all), v, iv, p32, a32, mse_coef)
-    else:
-        d_img = math.normalize_bwd(math.matmul(s_img, v_all), u, iu)
-        d_prof = math.normalize_bwd(math.matmul(s_prof, u_all), v, iv)
+    d_img, d_prof, dls = math.clip_bwd(gathered, logit_scale, lse, lse_all, comm.rank, 1.0 / (2.0 * n), uv, inv,
+                                       a32 if beta else None, p32 if beta else None, mse_coef)
     return loss, d_img, d_prof, dls
 
 

@@ -15,55 +15,81 @@ from oracle import coordination as OC
 
 
 class TorchMath:
-    """Reference arithmetic for the math interface of distributed.dp_clip (test double)."""
+    """Reference arithmetic for the math interface of distributed.dp_clip / dp_siglip (test double of HipClipMath):
+    `gathered` [world, 2, b, D] normalised embeddings; role 0 = my image rows against all profiles, role 1 = my profile
+    rows against all images."""
 
-    def normalize(self, x):
-        nrm = x.detach().norm(dim=1).clamp_min(1e-12)
-        return x.detach() / nrm[:, None], 1.0 / nrm
+    def normalize(self, a, p):
+        x = torch.stack((a.detach(), p.detach()))
+        nrm = x.norm(dim=2).clamp_min(1e-12)
+        return x / nrm[..., None], 1.0 / nrm
 
-    def logits(self, x_loc, y_all):
-        return x_loc @ y_all.T
+    @staticmethod
+    def _blocks(gathered, rank):
+        world, _, b, D = gathered.shape
+        u_all, v_all = gathered[:, 0].reshape(world * b, D), gathered[:, 1].reshape(world * b, D)
+        return gathered[rank, 0] @ v_all.T, gathered[rank, 1] @ u_all.T, rank * b, b
 
-    def block_fwd(self, S, logit_scale, off):
-        l = S * logit_scale.detach().exp()
-        lse = torch.logsumexp(l, 1)
-        idx = torch.arange(S.shape[0])
-        return lse, (lse - l[idx, off + idx]).sum()
-
-    def block_bwd(self, S, logit_scale, lse_own, lse_other, off, coef):
+    def clip_fwd(self, gathered, logit_scale, rank, mul):
+        s_img, s_prof, off, b = self._blocks(gathered, rank)
         scale = logit_scale.detach().exp()
-        l = S * scale
-        g = torch.exp(l - lse_own[:, None]) + torch.exp(l - lse_other[None, :])
-        idx = torch.arange(S.shape[0])
-        g[idx, off + idx] -= 2
-        g *= coef
-        S.copy_(g * scale)
-        return (g * l).sum()
+        idx = torch.arange(b)
+        lse = torch.stack((torch.logsumexp(s_img * scale, 1), torch.logsumexp(s_prof * scale, 1)))
+        diag = torch.stack(((s_img * scale)[idx, off + idx], (s_prof * scale)[idx, off + idx]))
+        return lse, (lse - diag).sum() * mul
 
-    def matmul(self, g, y_all):
-        return g @ y_all
-
-    def normalize_bwd(self, du, u, inv, x=None, other=None, mse_coef=0.0):
+    @staticmethod
+    def _norm_bwd(du, u, inv, x, other, mse_coef):
         dx = inv[:, None] * (du - u * (u * du).sum(1, keepdim=True))
         return dx + mse_coef * (x - other) if mse_coef else dx
 
-    def siglip_block_fwd(self, S, logit_scale, bias, off):
-        z = S * logit_scale.detach().exp() + bias.detach()
-        sg = -torch.ones_like(z)
-        idx = torch.arange(S.shape[0])
-        sg[idx, off + idx] = 1
-        return -torch.nn.functional.logsigmoid(sg * z).sum()
-
-    def siglip_block_bwd(self, S, logit_scale, bias, off, coef, want_param_grads):
+    def clip_bwd(self, gathered, logit_scale, lse, lse_all, rank, coef, uv, inv, image_emb=None, profile_emb=None,
+                 mse_coef=0.0):
+        world, _, b, D = gathered.shape
+        s_img, s_prof, off, _ = self._blocks(gathered, rank)
         scale = logit_scale.detach().exp()
-        l = S * scale
-        z = l + bias.detach()
-        sg = -torch.ones_like(z)
+        idx = torch.arange(b)
+        out, dls = [], None
+        for z, S in enumerate((s_img, s_prof)):
+            l = S * scale
+            g = torch.exp(l - lse[z][:, None]) + torch.exp(l - lse_all[:, 1 - z].reshape(-1)[None, :])
+            g[idx, off + idx] -= 2
+            g = g * coef
+            if z == 0:
+                dls = (g * l).sum()
+            y_all = gathered[:, 1 - z].reshape(world * b, D)
+            x, other = (image_emb, profile_emb) if z == 0 else (profile_emb, image_emb)
+            out.append(self._norm_bwd((g * scale) @ y_all, uv[z], inv[z], x, other, mse_coef))
+        return out[0], out[1], dls
+
+    @staticmethod
+    def _signs(S, off):
+        sg = -torch.ones_like(S)
         idx = torch.arange(S.shape[0])
         sg[idx, off + idx] = 1
-        g = -sg * coef * torch.sigmoid(-sg * z)
-        S.copy_(g * scale)
-        return ((g * l).sum(), g.sum()) if want_param_grads else (None, None)
+        return sg
+
+    def siglip_fwd(self, gathered, logit_scale, bias, rank, mul):
+        s_img, _, off, _ = self._blocks(gathered, rank)
+        z = s_img * logit_scale.detach().exp() + bias.detach()
+        return -torch.nn.functional.logsigmoid(self._signs(z, off) * z).sum() * mul
+
+    def siglip_bwd(self, gathered, logit_scale, bias, rank, coef, uv, inv, image_emb=None, profile_emb=None,
+                   mse_coef=0.0):
+        world, _, b, D = gathered.shape
+        s_img, s_prof, off, _ = self._blocks(gathered, rank)
+        scale = logit_scale.detach().exp()
+        out, dls, db = [], None, None
+        for z, S in enumerate((s_img, s_prof)):
+            l = S * scale
+            sg = self._signs(S, off)
+            g = -sg * coef * torch.sigmoid(-sg * (l + bias.detach()))
+            if z == 0:
+                dls, db = (g * l).sum(), g.sum()
+            y_all = gathered[:, 1 - z].reshape(world * b, D)
+            x, other = (image_emb, profile_emb) if z == 0 else (profile_emb, image_emb)
+            out.append(self._norm_bwd((g * scale) @ y_all, uv[z], inv[z], x, other, mse_coef))
+        return out[0], out[1], dls, db
 
     def sqdiff_sum(self, a, b):
         return ((a - b) ** 2).sum()
