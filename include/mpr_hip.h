@@ -70,6 +70,13 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats /* may 
                  int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
 int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add /* may be NULL */, int B, int H,
                    int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
+/* stride-2 data gradient + the data gradient of a parallel 1x1 / stride-2 / pad-0 shortcut convolution given on the
+ * half-resolution grid, add_even [B, H/2, W/2, C] (it only reaches the even pixels): the block-input gradient of a ResNet
+ * downsampling block (timm BasicBlock with downsample, behind src/image_encoder.py:24) without the 3/4-zero shortcut map.
+ * Geometries: mpr_conv_dgrad_add_even_supported != 0 */
+int mpr_conv_dgrad_add_even_supported(int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw);
+int mpr_conv_dgrad_s2(const void* dy, const void* w_dgrad, void* dx, const void* add_even, int B, int H, int W, int C,
+                      int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
 /* dw_oihw != NULL: workspace is zeroed, filled as [K][R][S][C] and permuted into (accumulate: added to) dw_oihw.
  * dw_oihw == NULL: the gradient stays in `workspace` as [K][R][S][C] -- the memory of a channels-last weight's
  * gradient -- zeroed first unless `accumulate` (then the split-K atomics add into what is there) */

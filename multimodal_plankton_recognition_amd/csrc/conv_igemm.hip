@@ -35,6 +35,8 @@ struct ConvGemmParams {
   unsigned long long* stamps; // timing experiments: per-workgroup phase time stamps (100 MHz), or NULL
   int dbg;                   // timing experiments: bit 2 / 3 = do not ISSUE the activation / weight DMA at all
   int par_rows, par_valid;   // stride-2 dgrad parity classes (LDS-DMA kernel): padded / real rows per class, 0 = off
+  const bf16_t* add_even;    // parity classes only: [B, Pm, Qm, Nout] added at the pixels (2 h2, 2 w2) -- the data gradient
+                             // of a 1x1 / stride-2 shortcut convolution, which is zero everywhere else
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {   // byte offset in a [rows][128 B] tile
@@ -518,6 +520,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     for (int r = rr; r < 64; r += RPP) {
       int m = m0 + slab * 64 + r - mbase;
       bool row_ok = m < (PAR ? p.par_valid : p.M);
+      const int mc = m;          // class-local row == pixel index of the half-resolution grid
       if (PAR && row_ok) {     // class-local row -> pixel (b, 2*h2 + par_h, 2*w2 + par_w) of the [B, 2*Pm, 2*Qm] gradient
         const uint32_t b = fdiv(m, p.div_pq);
         const uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
@@ -533,6 +536,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         if (p.add) {
           float g[8];
           unpack8(*reinterpret_cast<const uint4*>(p.add + o), g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += g[e];
+        }
+        if (PAR && cls == 0 && p.add_even) {
+          float g[8];
+          unpack8(*reinterpret_cast<const uint4*>(p.add_even + (size_t)mc * p.Nout + ncol), g);
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] += g[e];
         }
@@ -958,7 +967,7 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
     return rc;
   }
   ConvGemmParams p;
-  p.src = (const bf16_t*)x; p.wpk = (const bf16_t*)w_fwd; p.dst = (bf16_t*)y; p.add = nullptr; p.stats = stats;
+  p.src = (const bf16_t*)x; p.wpk = (const bf16_t*)w_fwd; p.dst = (bf16_t*)y; p.add = nullptr; p.add_even = nullptr; p.stats = stats;
   p.sH = H; p.sW = W; p.sC = C;
   p.src_bytes = (unsigned)((size_t)B * H * W * C * 2);
   p.wpk_bytes = (unsigned)((size_t)pad_to(K, 128) * pad_to(R * S * C, 64) * 2);
@@ -970,8 +979,21 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
 }
 
 // dx[B,H,W,C] = conv_transpose(dy[B,P,Q,K], w) (+ add[B,H,W,C] if given)
-int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add, int B, int H, int W,
-                   int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+static bool dgrad_parity_path(int B, int H, int W, int C, int K, int R, int S, int sh, int sw) {
+  // (mirrors launch_igemm: LDS-DMA kernel + stride 2 on even extents + more than one tap)
+  int mode, BM, BN;
+  igemm_config((long long)B * H * W, C, K, R * S, &mode, &BM, &BN);
+  return mode == 1 && sh == 2 && sw == 2 && H % 2 == 0 && W % 2 == 0 && g_dgrad_parity >= 1 && R * S > 1;
+}
+
+// Can mpr_conv_dgrad take `add_even` for this geometry (stride-2 data gradient on the parity-class path)?
+int mpr_conv_dgrad_add_even_supported(int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw) {
+  (void)ph; (void)pw;
+  return C % 8 == 0 && K % 8 == 0 && dgrad_parity_path(B, H, W, C, K, R, S, sh, sw) ? 1 : 0;
+}
+
+static int conv_dgrad_impl(const void* dy, const void* w_dgrad, void* dx, const void* add, const void* add_even, int B, int H,
+                           int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
   MPR_REQUIRE(dy && w_dgrad && dx, "mpr_conv_dgrad: null pointer");
   MPR_REQUIRE(C % 8 == 0 && K % 8 == 0, "mpr_conv_dgrad: C (%d) and K (%d) must be multiples of 8", C, K);
   MPR_REQUIRE((sh == 1 || sh == 2) && (sw == 1 || sw == 2), "mpr_conv_dgrad: strides must be 1 or 2 (got %d,%d)", sh, sw);
@@ -979,6 +1001,8 @@ int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* ad
   MPR_REQUIRE(P > 0 && Q > 0, "mpr_conv_dgrad: empty output");
   MPR_REQUIRE((long long)B * H * W * C < (1ll << 31) && (long long)B * P * Q * K < (1ll << 31),
               "mpr_conv_dgrad: tensor exceeds 2^31 elements");
+  MPR_REQUIRE(!add_even || (dgrad_parity_path(B, H, W, C, K, R, S, sh, sw) && P == H / 2 && Q == W / 2),
+              "mpr_conv_dgrad_s2: geometry not on the parity-class path (ask mpr_conv_dgrad_add_even_supported)");
   if (mpr_win_eligible((long long)B * H * W, H, W, K, C, R, S, sh, sw, ph, pw, g_dma_min_rows)) {
     void* tok = mpr_prof_begin(7, 2.0 * (double)B * H * W * C * 9.0 * K, (hipStream_t)stream);      // kind 7: window dgrad
     mpr_prof_bytes(tok, 2.0 * ((double)B * P * Q * K + 9.0 * C * K + (double)B * H * W * C * (add ? 2 : 1)));
@@ -988,6 +1012,7 @@ int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* ad
   }
   ConvGemmParams p;
   p.src = (const bf16_t*)dy; p.wpk = (const bf16_t*)w_dgrad; p.dst = (bf16_t*)dx; p.add = (const bf16_t*)add;
+  p.add_even = (const bf16_t*)add_even;
   p.stats = nullptr;
   p.sH = P; p.sW = Q; p.sC = K;
   p.src_bytes = (unsigned)((size_t)B * P * Q * K * 2);
@@ -996,6 +1021,20 @@ int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* ad
   p.R = R; p.S = S; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
   p.Pm = H; p.Qm = W; p.div_pq = make_fastdiv(H * W); p.div_q = make_fastdiv(W);
   return launch_igemm(true, p, (hipStream_t)stream);
+}
+
+int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* add, int B, int H, int W,
+                   int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+  return conv_dgrad_impl(dy, w_dgrad, dx, add, nullptr, B, H, W, C, K, R, S, sh, sw, ph, pw, stream);
+}
+
+// Stride-2 data gradient + the gradient of a parallel 1x1 / stride-2 / pad-0 convolution given on the HALF-resolution
+// grid (add_even [B, H/2, W/2, C]: it only reaches the even pixels) -- the block-input gradient of a ResNet
+// downsampling block without materialising the 3/4-zero full-resolution shortcut gradient.
+int mpr_conv_dgrad_s2(const void* dy, const void* w_dgrad, void* dx, const void* add_even, int B, int H, int W,
+                      int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+  MPR_REQUIRE(add_even, "mpr_conv_dgrad_s2: null add_even");
+  return conv_dgrad_impl(dy, w_dgrad, dx, nullptr, add_even, B, H, W, C, K, R, S, sh, sw, ph, pw, stream);
 }
 
 // Is the data gradient with fused BatchNorm-backward reduction (mpr_conv_dgrad_bn) available for this geometry?

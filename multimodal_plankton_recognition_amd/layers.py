@@ -189,6 +189,11 @@ class BasicBlockFn(torch.autograd.Function):
         if wd is not None:
             dxd, dgd, dbd, _ = ops.bn_bwd(dz, None, xd, gd, std, MASK_NONE, beta=bd)
             dwd = ops.conv_wgrad(x, dxd, cd, wd)
+            # the shortcut conv's data gradient lives on the even pixels only: half-resolution GEMM, added by the
+            # parity-class kernel of conv1's stride-2 data gradient
+            dx = ops.conv_dgrad_shortcut(dx1, wd1, c1, x.shape, dxd, wdd, cd)
+            if dx is not None:
+                return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None
             skip = ops.conv_dgrad(dxd, wdd, cd, x.shape)
         else:
             dgd = dbd = dwd = None

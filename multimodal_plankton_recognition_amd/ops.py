@@ -240,6 +240,23 @@ def conv_dgrad(dy, wd, g, x_shape, add=None):
     return dx
 
 
+def conv_dgrad_shortcut(dy, wd, g, x_shape, dy_sc, wd_sc, g_sc):
+    """Block-input gradient of a downsampling BasicBlock: data gradient of the stride-2 3x3 conv (dy, wd, g) + data gradient
+    of the parallel 1x1 / stride-2 shortcut conv (dy_sc, wd_sc, g_sc).  The shortcut's gradient only reaches the even
+    pixels: it is formed on the half-resolution grid (a plain GEMM, a quarter of the rows) and added there by the
+    parity-class kernel, instead of a full-resolution 3/4-zero map written and read back.  None: geometry not served."""
+    if len(x_shape) != 4 or (g_sc.R, g_sc.S, g_sc.sh, g_sc.sw, g_sc.ph, g_sc.pw) != (1, 1, 2, 2, 0, 0):
+        return None
+    B, H, W, C = x_shape
+    if not N.query('mpr_conv_dgrad_add_even_supported', B, H, W, C, g.K, *g.tail) or tuple(dy_sc.shape[1:3]) != (H // 2, W // 2):
+        return None
+    half = torch.empty((B, H // 2, W // 2, C), dtype=BF16, device=dy.device)
+    N.call('mpr_conv_dgrad', dy_sc, wd_sc, half, None, B, H // 2, W // 2, C, g_sc.K, 1, 1, 1, 1, 0, 0)
+    dx = torch.empty(x_shape, dtype=BF16, device=dy.device)
+    N.call('mpr_conv_dgrad_s2', dy, wd, dx, half, B, H, W, C, g.K, *g.tail)
+    return dx
+
+
 AUTOTUNE = os.environ.get('MPR_AUTOTUNE', '1') != '0'
 _FIXED_WGRAD_WGS = int(os.environ.get('MPR_WGRAD_WGS', '0'))      # experiments: one target for every geometry
 _wgrad_split = {}          # geometry -> (window kernel?, workgroup-count target of the split over pixels)
