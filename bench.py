@@ -251,6 +251,10 @@ def main():
                'wgrad_dma': family([2], 'conv_wgrad_dma_kernel (other weight gradients)', 'wgrad_dma')}
         dom = family([6, 7], 'conv_win_kernel (shifted-window implicit-GEMM conv: forward + data-gradient instantiations, 13 of '
                              "ResNet-18's 20 convolutions, 80 % of its FLOPs)", 'win_fwd_dgrad')
+        if dom['launches'] == 0:
+            # cards without 3x3 / stride-1 convolutions (transformer encoders: every linear is a one-tap implicit GEMM)
+            dom = family([0, 1], 'conv_igemm_dma_kernel (LDS-DMA implicit GEMM: the linears of the transformer encoders, forward + '
+                                 'data gradient)', 'dma_fwd_dgrad')
         out = {
             'metric': 'samples/sec (image+profile pairs) for train_multi', 'value': round(B * world * args.steps / elapsed, 1),
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
