@@ -47,25 +47,33 @@ __device__ __forceinline__ s16x4 wgw_read_tr(uint32_t lds_addr) {
   return v;
 }
 
-template <int KH>
-__global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParams p) {
+// PS = 2 (64 output channels only): a chunk is 128 pixels and a second set of six waves works on its upper 64 -- twelve
+// waves per workgroup as at KH = 2, where six (1.5 per SIMD) left every wave's read -> wait -> MFMA chain exposed: the loop
+// took the same ~2700 cycles per 64 pixels with half the MFMA work.  The two halves' accumulators are summed through LDS
+// at the end.  The ring holds two chunks + both halos then (384 rows; 512 allocated).
+template <int KH, int PS = 1>
+__global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const WgwParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NW = 6 * KH;
-  constexpr int RING = 256;                    // x ring rows (128 B each: 64 channels)
+  static_assert(KH * PS <= 2, "twelve waves at most");
+  constexpr int NW = 6 * KH * PS;
+  constexpr int CHUNK = 64 * PS;               // pixels per chunk
+  constexpr int RING = PS == 1 ? 256 : 512;    // x ring rows (128 B each: 64 channels); PS = 2 needs 384, a power of two is free
   constexpr int XBYTES = RING * 128;
   constexpr int DROW = 128 * KH;               // dy stage row bytes (64*KH output channels)
-  constexpr int DSTAGE = 64 * DROW;
-  constexpr int D_INSTR = DSTAGE / 1024;       // 8*KH DMA instructions per dy chunk
+  constexpr int DSTAGE = CHUNK * DROW;
+  constexpr int D_INSTR = DSTAGE / 1024;       // 8*KH*PS DMA instructions per dy chunk
   constexpr int D_IT = (D_INSTR + NW - 1) / NW;
-  constexpr int XI_IT = (24 + NW - 1) / NW;    // initial window: up to 64 + 2*64 rows = 24 instructions
-  constexpr int XC_IT = (8 + NW - 1) / NW;     // per chunk: 64 new rows = 8 instructions
+  constexpr int XI_IT = (8 * PS + 16 + NW - 1) / NW;    // initial window: up to CHUNK + 2*64 rows
+  constexpr int XC_IT = (8 * PS + NW - 1) / NW;         // per chunk: CHUNK new rows
+  auto ring = [](int G) -> int { return G & (RING - 1); };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [x ring 32 KB][dy stage 0][dy stage 1]
   unsigned char* const dyst = smem + XBYTES;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address of smem
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid % 3, wh = (wid / 3) & 1, wk = wid / 6;      // filter row, channel half, output-channel slab
+  const int wr = wid % 3, wh = (wid / 3) & 1;                      // filter row, channel half
+  const int wk = PS == 1 ? wid / 6 : 0, wp = PS == 1 ? 0 : wid / 6;   // output-channel slab | pixel half of the chunk
   // consecutive blocks share the pixel range (their dy / x rows come from the same L2 lines)
   const int cb = blockIdx.x % p.ncb;
   const int kt = (blockIdx.x / p.ncb) % p.nkt;
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
   // 64-B segment swizzle on the source side: logical chunk = ((pc >> 2) ^ ((row >> 1) & 1)) << 2 | (pc & 3)
   auto x_off = [&](int G8) -> uint32_t {
     const int G = G8 + (lane >> 3);
-    const int row = G & (RING - 1);
+    const int row = ring(G);
     const int pc = lane & 7;
     const int lc = (((pc >> 2) ^ ((row >> 1) & 1)) << 2) | (pc & 3);
     uint32_t pix;
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
   };
   auto fire_x8 = [&](int G8, uint32_t v) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rs_x, (__attribute__((address_space(3))) void*)(smem + (G8 & (RING - 1)) * 128), 16, v, 0, 0, 0);
+        rs_x, (__attribute__((address_space(3))) void*)(smem + ring(G8) * 128), 16, v, 0, 0, 0);
   };
   auto issue_x8 = [&](int G8) { fire_x8(G8, x_off(G8)); };
   // dy rows of chunk ci -> stage ci & 1: instruction I covers 1024 / DROW rows
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
     const int key = CH == 16 ? (row & 3) : ((row >> 1) & 1);
     const int lc = (((pc >> 2) ^ key) << 2) | (pc & 3);
     uint32_t pix;
-    return pixel_of(ci * 64 + row, pix) ? pix * (uint32_t)(2 * p.K) + (uint32_t)((kt * 64 * KH + lc * 8) * 2)
+    return pixel_of(ci * CHUNK + row, pix) ? pix * (uint32_t)(2 * p.K) + (uint32_t)((kt * 64 * KH + lc * 8) * 2)
                                         : 0xFFFFFFF0u;
   };
   // The source offsets of a chunk's DMA (two fastdivs per lane and instruction) are computed ONE CHUNK AHEAD, underneath
@@ -119,11 +127,11 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
   // (Computed right there they cost every wave ~900 cycles with the matrix pipe idle: all waves sit at the same point.)
   uint32_t vx[XC_IT], vd[D_IT];
   auto prep_chunk = [&](int ci) {       // chunk ci: its 64 leading-edge ring rows and its dy rows
-    const int lo = ci * 64 + p.halo8;
+    const int lo = ci * CHUNK + p.halo8;                  // (first raster row behind the window of chunk ci - 1)
 #pragma unroll
     for (int j = 0; j < XC_IT; ++j) {
       const int I = wid + j * NW;
-      vx[j] = (8 % NW == 0 || I < 8) ? x_off(lo + 8 * I) : 0xFFFFFFF0u;
+      vx[j] = ((8 * PS) % NW == 0 || I < 8 * PS) ? x_off(lo + 8 * I) : 0xFFFFFFF0u;
     }
 #pragma unroll
     for (int j = 0; j < D_IT; ++j) {
@@ -132,12 +140,12 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
     }
   };
   auto fire_chunk = [&](int ci) {
-    const int lo = ci * 64 + p.halo8;
+    const int lo = ci * CHUNK + p.halo8;
     unsigned char* st = dyst + (ci & 1) * DSTAGE;
 #pragma unroll
     for (int j = 0; j < XC_IT; ++j) {
       const int I = wid + j * NW;
-      if (8 % NW == 0 || I < 8) fire_x8(lo + 8 * I, vx[j]);
+      if ((8 * PS) % NW == 0 || I < 8 * PS) fire_x8(lo + 8 * I, vx[j]);
     }
 #pragma unroll
     for (int j = 0; j < D_IT; ++j) {
@@ -166,12 +174,12 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
   for (int i = 0; i < 2; ++i) {
     const int seg = wk * 2 + i;                                // 64-B segment = 32 output channels
     const int key = KH == 2 ? (lq & 3) : ((lq >> 1) & 1);
-    a_rd[i] = rowl * DROW + ((seg ^ key) << 6) + inseg;
+    a_rd[i] = (wp * 64 + rowl) * DROW + ((seg ^ key) << 6) + inseg;
   }
 
   // ---- prologue: window of the first chunk + its dy
   {
-    const int lo = c0 * 64 - p.halo8, hi = c0 * 64 + 64 + p.halo8;
+    const int lo = c0 * CHUNK - p.halo8, hi = c0 * CHUNK + CHUNK + p.halo8;
 #pragma unroll
     for (int j = 0; j < XI_IT; ++j) {
       const int G8 = lo + 8 * (wid + j * NW);
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int d = (wr - 1) * p.Wp + (s - 1);
-        const int r0 = (ci * 64 + ks * 16 + rowl + d) & (RING - 1);
+        const int r0 = ring(ci * CHUNK + wp * 64 + ks * 16 + rowl + d);
         const int r1 = (r0 + 4) & (RING - 1);
         const int lowb = ((wh ^ ((r0 >> 1) & 1)) << 6) + inseg;       // (r0 + 4) >> 1 has the parity of r0 >> 1
         rb[buf][s][0] = wgw_read_tr(lds0 + r0 * 128 + lowb);
@@ -266,6 +274,29 @@ __global__ __launch_bounds__(384 * KH) void conv_wgrad_win_kernel(const WgwParam
   if (p.dbg & 1) {      // timing experiment: no epilogue (one conditional store keeps the accumulators alive)
     if (acc[0][0][0] + acc[1][2][5] == 12345.f) p.dw[0] = 1.f;
     return;
+  }
+  if (PS == 2) {
+    // the upper pixel half's accumulators join the lower half's through LDS: 3 tiles (72 KB) per pass
+    float* const red = reinterpret_cast<float*>(smem);
+    const int role = wid % 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __syncthreads();
+      if (wp == 1) {
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red[((role * 3 + s2) * 16 + e) * 64 + lane] = acc[i][s2][e];
+      }
+      __syncthreads();
+      if (wp == 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][s2][e] += red[((role * 3 + s2) * 16 + e) * 64 + lane];
+      }
+    }
+    if (wp == 1) return;
   }
   // D[k (regs)][n (lanes)], 128 B contiguous per half-wave: plain stores into this pixel split's slice (summed by
   // wgw_reduce_kernel) when the caller lent scratch memory -- the chip adds ~1.3 TB/s of fp32 atomics but stores
@@ -357,8 +388,9 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   p.Wp = W + 1; p.img = (H + 1) * (W + 1); p.Gtot = B * p.img; p.halo8 = (W + 2 + 7) / 8 * 8;
   p.Ng = 9 * C; p.ncb = C / 64;
   const int KH = K % 128 == 0 ? 2 : 1;
+  const int PS = (KH == 1 && g_wgw_on != 2) ? 2 : 1;      // (mpr_conv_set_wgrad_window(2): six-wave form, comparisons)
   p.nkt = K / (64 * KH);
-  p.total_chunks = ceil_div(p.Gtot, 64);
+  p.total_chunks = ceil_div(p.Gtot, 64 * PS);
   const int tiles = p.ncb * p.nkt;
   int nsplit = (target_wgs > 0 ? target_wgs : g_wgw_target) / tiles;
   if (nsplit > ceil_div(p.total_chunks, 4)) nsplit = ceil_div(p.total_chunks, 4);
@@ -373,8 +405,15 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   // partial slices instead of atomics when the caller lent enough scratch for THIS launch (one-shot)
   p.part = (scratch && (long long)nsplit * K * p.Ng <= scratch_floats) ? scratch : nullptr;
   const dim3 grid(nsplit * tiles);
-  const size_t lds = 256 * 128 + 2 * 64 * 128 * (size_t)KH;
-  if (KH == 2) {
+  const size_t lds = PS == 2 ? (size_t)512 * 128 + 2 * 128 * 128 : 256 * 128 + 2 * 64 * 128 * (size_t)KH;
+  if (PS == 2) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    conv_wgrad_win_kernel<1, 2><<<grid, 768, lds, st>>>(p);
+  } else if (KH == 2) {
     static bool attr_set = false;
     if (!attr_set) {
       hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
