@@ -51,20 +51,22 @@ __device__ __forceinline__ s16x4 wgw_read_tr(uint32_t lds_addr) {
 // waves per workgroup as at KH = 2, where six (1.5 per SIMD) left every wave's read -> wait -> MFMA chain exposed: the loop
 // took the same ~2700 cycles per 64 pixels with half the MFMA work.  The two halves' accumulators are summed through LDS
 // at the end.  The ring holds two chunks + both halos then (384 rows; 512 allocated).
-template <int KH, int PS = 1>
+// PB = 2: every wave walks two 64-pixel blocks per chunk (8 k-steps between barriers instead of 4): the per-chunk fixed
+// costs -- barrier skew, DMA issue, the first fragments' LDS latency, ~1400 cycles -- are paid half as often.
+template <int KH, int PS = 1, int PB = 1>
 __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const WgwParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(KH * PS <= 2, "twelve waves at most");
   constexpr int NW = 6 * KH * PS;
-  constexpr int CHUNK = 64 * PS;               // pixels per chunk
-  constexpr int RING = PS == 1 ? 256 : 512;    // x ring rows (128 B each: 64 channels); PS = 2 needs 384, a power of two is free
+  constexpr int CHUNK = 64 * PS * PB;          // pixels per chunk
+  constexpr int RING = CHUNK == 64 ? 256 : 512;   // x ring rows (128 B each: 64 channels): 2 chunks + both halos, power of two
   constexpr int XBYTES = RING * 128;
   constexpr int DROW = 128 * KH;               // dy stage row bytes (64*KH output channels)
   constexpr int DSTAGE = CHUNK * DROW;
   constexpr int D_INSTR = DSTAGE / 1024;       // 8*KH*PS DMA instructions per dy chunk
   constexpr int D_IT = (D_INSTR + NW - 1) / NW;
-  constexpr int XI_IT = (8 * PS + 16 + NW - 1) / NW;    // initial window: up to CHUNK + 2*64 rows
-  constexpr int XC_IT = (8 * PS + NW - 1) / NW;         // per chunk: CHUNK new rows
+  constexpr int XI_IT = (CHUNK / 8 + 16 + NW - 1) / NW;    // initial window: up to CHUNK + 2*64 rows
+  constexpr int XC_IT = (CHUNK / 8 + NW - 1) / NW;         // per chunk: CHUNK new rows
   auto ring = [](int G) -> int { return G & (RING - 1); };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [x ring 32 KB][dy stage 0][dy stage 1]
   unsigned char* const dyst = smem + XBYTES;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
 #pragma unroll
     for (int j = 0; j < XC_IT; ++j) {
       const int I = wid + j * NW;
-      vx[j] = ((8 * PS) % NW == 0 || I < 8 * PS) ? x_off(lo + 8 * I) : 0xFFFFFFF0u;
+      vx[j] = ((CHUNK / 8) % NW == 0 || I < CHUNK / 8) ? x_off(lo + 8 * I) : 0xFFFFFFF0u;
     }
 #pragma unroll
     for (int j = 0; j < D_IT; ++j) {
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
 #pragma unroll
     for (int j = 0; j < XC_IT; ++j) {
       const int I = wid + j * NW;
-      if ((8 * PS) % NW == 0 || I < 8 * PS) fire_x8(lo + 8 * I, vx[j]);
+      if ((CHUNK / 8) % NW == 0 || I < CHUNK / 8) fire_x8(lo + 8 * I, vx[j]);
     }
 #pragma unroll
     for (int j = 0; j < D_IT; ++j) {
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   for (int i = 0; i < 2; ++i) {
     const int seg = wk * 2 + i;                                // 64-B segment = 32 output channels
     const int key = KH == 2 ? (lq & 3) : ((lq >> 1) & 1);
-    a_rd[i] = (wp * 64 + rowl) * DROW + ((seg ^ key) << 6) + inseg;
+    a_rd[i] = (wp * 64 * PB + rowl) * DROW + ((seg ^ key) << 6) + inseg;
   }
 
   // ---- prologue: window of the first chunk + its dy
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int d = (wr - 1) * p.Wp + (s - 1);
-        const int r0 = ring(ci * CHUNK + wp * 64 + ks * 16 + rowl + d);
+        const int r0 = ring(ci * CHUNK + wp * 64 * PB + ks * 16 + rowl + d);
         const int r1 = (r0 + 4) & (RING - 1);
         const int lowb = ((wh ^ ((r0 >> 1) & 1)) << 6) + inseg;       // (r0 + 4) >> 1 has the parity of r0 >> 1
         rb[buf][s][0] = wgw_read_tr(lds0 + r0 * 128 + lowb);
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
     };
     issue_reads(0, 0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 4 * PB; ++ks) {
       const int cur = ks & 1;
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(ra[cur][0][0]), "+v"(ra[cur][0][1]), "+v"(ra[cur][1][0]), "+v"(ra[cur][1][1]),
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
                      "+v"(rb[cur][2][0]), "+v"(rb[cur][2][1])
                    :
                    : "memory");
-      if (ks < 3) issue_reads(cur ^ 1, ks + 1);
+      if (ks < 4 * PB - 1) issue_reads(cur ^ 1, ks + 1);
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 af[2], bfr[3];
 #pragma unroll
@@ -388,9 +390,12 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   p.Wp = W + 1; p.img = (H + 1) * (W + 1); p.Gtot = B * p.img; p.halo8 = (W + 2 + 7) / 8 * 8;
   p.Ng = 9 * C; p.ncb = C / 64;
   const int KH = K % 128 == 0 ? 2 : 1;
-  const int PS = (KH == 1 && g_wgw_on != 2) ? 2 : 1;      // (mpr_conv_set_wgrad_window(2): six-wave form, comparisons)
+  const int PS = (KH == 1 && g_wgw_on != 2) ? 2 : 1;      // (mpr_conv_set_wgrad_window(2): round-1 forms, comparisons)
+  // (two pixel blocks per chunk at K % 128 == 0: 170 -> 158 us on layer2's shape, 149 -> 155 on layer3's, 168 -> 170 on
+  //  layer4's -- the barrier is not what the loop loses; kept as mpr_conv_set_wgrad_window(3) for experiments)
+  const int PB = (KH == 2 && g_wgw_on == 3) ? 2 : 1;
   p.nkt = K / (64 * KH);
-  p.total_chunks = ceil_div(p.Gtot, 64 * PS);
+  p.total_chunks = ceil_div(p.Gtot, 64 * PS * PB);
   const int tiles = p.ncb * p.nkt;
   int nsplit = (target_wgs > 0 ? target_wgs : g_wgw_target) / tiles;
   if (nsplit > ceil_div(p.total_chunks, 4)) nsplit = ceil_div(p.total_chunks, 4);
@@ -405,8 +410,15 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   // partial slices instead of atomics when the caller lent enough scratch for THIS launch (one-shot)
   p.part = (scratch && (long long)nsplit * K * p.Ng <= scratch_floats) ? scratch : nullptr;
   const dim3 grid(nsplit * tiles);
-  const size_t lds = PS == 2 ? (size_t)512 * 128 + 2 * 128 * 128 : 256 * 128 + 2 * 64 * 128 * (size_t)KH;
-  if (PS == 2) {
+  const size_t lds = PS * PB == 2 ? (size_t)512 * 128 + 2 * 128 * 128 * (size_t)KH : 256 * 128 + 2 * 64 * 128 * (size_t)KH;
+  if (PB == 2) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    conv_wgrad_win_kernel<2, 1, 2><<<grid, 768, lds, st>>>(p);
+  } else if (PS == 2) {
     static bool attr_set = false;
     if (!attr_set) {
       hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -1,4 +1,5 @@
-"""K = 64 sliding-window weight gradient: twelve-wave pixel-split form (default) against the six-wave form and fp32 torch."""
+"""Sliding-window weight gradient: round-2 forms (K = 64: twelve waves on two pixel halves; K % 128 == 0: two pixel blocks per
+chunk) against the round-1 forms and fp32 torch."""
 import sys, torch
 sys.path.insert(0, '.')
 from multimodal_plankton_recognition_amd import ops, _native as N
@@ -12,8 +13,8 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
-for B, H, W in [(512, 56, 56), (64, 56, 56), (300, 28, 28), (37, 19, 23), (512, 7, 7), (9, 56, 40)]:
-    C = K = 64
+for B, H, W, C in [(512, 56, 56, 64), (64, 56, 56, 64), (37, 19, 23, 64), (512, 28, 28, 128), (512, 14, 14, 256), (512, 7, 7, 512), (40, 28, 20, 128), (33, 9, 11, 256)]:
+    K = C
     g = ops.ConvGeom((K, C, 3, 3), 1, 1)
     x = torch.randn(B, H, W, C, device='cuda').to(torch.bfloat16)
     dy = (torch.randn(B, H, W, K, device='cuda') * 0.1).to(torch.bfloat16)
@@ -22,7 +23,7 @@ for B, H, W in [(512, 56, 56), (64, 56, 56), (300, 28, 28), (37, 19, 23), (512, 
         ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (K, C, 3, 3), dy.float().permute(0, 3, 1, 2), padding=1)
     for tgt in (256, 512):
         N.query('mpr_conv_set_wgrad_target_wgs', tgt)
-        for name, mode in [('12 waves', 1), ('6 waves', 2)]:
+        for name, mode in [('round 2', 1), ('round 1', 2)]:
             N.query('mpr_conv_set_wgrad_window', mode)
             dw = ops.conv_wgrad(x, dy, g, (K, C, 3, 3))
             t = timeit(lambda: ops.conv_wgrad(x, dy, g, (K, C, 3, 3)))
