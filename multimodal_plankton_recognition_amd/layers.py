@@ -316,7 +316,7 @@ class LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = ops.gemm(dy, weight) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm(dy, x, trans_a=True)
+        dw = ops.linear_wgrad(dy, x, weight)
         db = ops.gemm(_ones(dy.shape[0], dy.device), dy, trans_a=True).reshape(-1) if ctx.has_bias else None
         return dx, dw, db
 

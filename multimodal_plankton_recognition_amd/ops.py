@@ -857,6 +857,30 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, alpha=1.0, bet
     return out
 
 
+def linear_wgrad(dy, x, weight):
+    """dW = dy^T x of an nn.Linear (exact fp32).  With optimizer-owned gradient memory it is ACCUMULATED there on the
+    weight-gradient side stream -- a leaf of the backward graph, off the dependent chain (the projections sit in the
+    forward / backward junction, where nothing else runs) -- and None is returned; otherwise the gradient tensor."""
+    tgt = grad_target(weight)
+    Nout, K = weight.shape
+    if tgt is None or not tgt.is_contiguous():
+        return gemm(dy, x, trans_a=True)
+    args = (dy, x, tgt, None, Nout, K, dy.shape[0], dy.shape[1], x.shape[1], K, 1, 0, 1.0, 1.0, 1, 0, 0, 0)
+    if ASYNC_WGRAD:
+        cur, side = _wgrad_stream(dy.device.index)
+        side.wait_stream(cur)
+        N.call('mpr_gemm_f32', *args, stream_handle=side.cuda_stream)
+        _note_arena_stream(dy.device.index, side)
+        if KEEPALIVE_WGRAD_OPERANDS and _join_queued[0]:
+            _wgrad_keepalive.append((x, dy))
+        else:
+            x.record_stream(side)
+            dy.record_stream(side)
+    else:
+        N.call('mpr_gemm_f32', *args)
+    return None
+
+
 def tail_fwd(feat, meta, denom, p_drop, seed):
     B, Fd = feat.shape
     Mm = 0 if meta is None else meta.shape[1]

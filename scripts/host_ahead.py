@@ -1,0 +1,36 @@
+"""Is the host ahead of the GPU in the C3 step loop?  Host enqueue time per step against the GPU's step time, and the
+depth of the launch backlog (GPU time still queued when the host finishes enqueuing a step)."""
+import sys, time, torch, yaml
+sys.path.insert(0, '.')
+import bench
+from multimodal_plankton_recognition_amd.model import MultiModel
+card = yaml.safe_load(open(bench.CARD))
+B, T = card['bs'], card['target_size']
+dev = torch.device('cuda', 0)
+torch.manual_seed(0)
+model = MultiModel(card['dim_embedding'], card['image_encoder_args'], card['profile_encoder_args'], card['coordination_args'],
+                   card['optim_args']).to(dev).train()
+opt = model.configure_optimizers()
+batch = bench.synthetic_batch(B, T, dev, 1234)
+batch['buckets'] = 1
+def one_step():
+    opt.zero_grad()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    opt.step()
+    return loss
+for _ in range(8): one_step()
+torch.cuda.synchronize()
+n = 30
+host = []
+t0 = time.perf_counter()
+for i in range(n):
+    a = time.perf_counter()
+    one_step()
+    host.append(time.perf_counter() - a)
+t_enq = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+host.sort()
+print(f'host enqueue per step: median {host[n // 2] * 1e3:.2f} ms (min {host[0] * 1e3:.2f}, max {host[-1] * 1e3:.2f}); '
+      f'GPU per step {t_all / n * 1e3:.2f} ms; backlog when the host is done: {(t_all - t_enq) * 1e3:.1f} ms')
