@@ -38,6 +38,7 @@ struct WinParams {
   // that went through a ReLU, so the epilogue applies the ReLU mask and accumulates the two BatchNorm-backward sums
   // (sum dz, sum dz * xhat) into `stats` -- the separate reduce pass over (dy, y, x) disappears.
   int mask_mode;               // 1: mask = mask_y > 0;  2: mask = bf16(bn_x * scale + shift) > 0 (ReLU mask recomputed)
+  int coef_off;                // byte offset in dynamic LDS of the [4][BN] fp32 table of BatchNorm coefficients (BNB)
   const bf16_t* mask_y;        // [B,H,W,Nout] (mode 1)
   const bf16_t* bn_x;          // [B,H,W,Nout] BatchNorm input: xhat = (bn_x - mean) * invstd
   const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;   // [Nout]
@@ -58,8 +59,12 @@ __device__ __forceinline__ void wait_vmcnt_win() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int STAGES, bool DGRAD, bool ADD = false, bool BNB = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && !BNB ? 4 : 2)) void conv_win_kernel(const WinParams p) {
+// BNB: 0 = plain; 1 = BatchNorm-backward fusion with the ReLU mask read from mask_y; 2 = ... with the mask recomputed from
+// the BatchNorm input (compile-time: the two modes keep different operands alive, and the 8-wave tile must stay under 128
+// VGPRs for its second workgroup per CU -- at one per CU nothing runs beside a workgroup's prologue and epilogue:
+// +100 us per layer2 launch, five times what the extra map read costs)
+template <int WM, int WN, int TM, int TN, int STAGES, bool DGRAD, bool ADD = false, int BNB = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win_kernel(const WinParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WM * WN, T = 64 * NW;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -243,17 +248,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && !BNB ? 4 : 2)) void 
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  // BatchNorm-backward fusion: this thread's 8 channels are fixed (ncol), so are their coefficients
-  float bmu[8], bis[8], bsc[8], bsh[8];
+  // BatchNorm-backward fusion: the coefficients of this tile's BN channels live in LDS ([mean | invstd | scale | shift][BN],
+  // behind everything the epilogue stages: registers are what keeps the second workgroup off the CU)
+  float* const coef = reinterpret_cast<float*>(smem + p.coef_off);
   if (BNB) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int n = col_ok ? ncol + e : 0;
-      bmu[e] = p.bn_mean[n];
-      bis[e] = p.bn_invstd[n];
-      bsc[e] = p.mask_mode == 2 ? p.bn_scale[n] : 0.f;
-      bsh[e] = p.mask_mode == 2 ? p.bn_shift[n] : 0.f;
+    if (tid < BN) {
+      const int n = n0 + tid < p.Nout ? n0 + tid : 0;
+      coef[tid] = p.bn_mean[n];
+      coef[BN + tid] = p.bn_invstd[n];
+      if (BNB == 2) {
+        coef[2 * BN + tid] = p.bn_scale[n];
+        coef[3 * BN + tid] = p.bn_shift[n];
+      }
     }
+    // (published by the barrier that opens the first staging pass)
   }
   // dz = mask * q (q: the bf16-rounded gradient values), sums of dz and dz * xhat; returns the masked, re-packed group.
   // xv / yv: this group of the BatchNorm input / of the mask source, loaded by the caller (all rows at once: the loop
@@ -261,19 +269,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && !BNB ? 4 : 2)) void 
   auto bnb_group = [&](float* q, const uint4& xv, const uint4& yv) -> uint4 {
     float xf[8];
     unpack8(xv, xf);
-    if (p.mask_mode == 1) {
+    if (BNB == 1) {
       float ym[8];
       unpack8(yv, ym);
 #pragma unroll
       for (int e = 0; e < 8; ++e) q[e] = ym[e] > 0.f ? q[e] : 0.f;
     } else {
+      // bf16(v) > 0 <=> v > 0: rounding keeps the sign, and bf16 has fp32's exponent range
+      const float4 c0 = *reinterpret_cast<const float4*>(coef + 2 * BN + ch * 8), c1 = *reinterpret_cast<const float4*>(coef + 2 * BN + ch * 8 + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(coef + 3 * BN + ch * 8), h1 = *reinterpret_cast<const float4*>(coef + 3 * BN + ch * 8 + 4);
+      const float sc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) q[e] = round_bf16(fmaf(xf[e], bsc[e], bsh[e])) > 0.f ? q[e] : 0.f;
+      for (int e = 0; e < 8; ++e) q[e] = fmaf(xf[e], sc[e], sh[e]) > 0.f ? q[e] : 0.f;
     }
+    const float4 m0 = *reinterpret_cast<const float4*>(coef + ch * 8), m1 = *reinterpret_cast<const float4*>(coef + ch * 8 + 4);
+    const float4 i0 = *reinterpret_cast<const float4*>(coef + BN + ch * 8), i1 = *reinterpret_cast<const float4*>(coef + BN + ch * 8 + 4);
+    const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, is[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       s1[e] += q[e];
-      s2[e] += q[e] * (xf[e] - bmu[e]) * bis[e];
+      s2[e] += q[e] * (xf[e] - mu[e]) * is[e];
     }
     return pack8(q);
   };
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && !BNB ? 4 : 2)) void 
         for (int n = 0; n < NR; ++n) {
           const size_t o = (size_t)(pix[n] != 0xFFFFFFFFu ? pix[n] : 0u) * p.Nout + (col_ok ? ncol : 0);
           xv[n] = *reinterpret_cast<const uint4*>(p.bn_x + o);
-          yv[n] = p.mask_mode == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
+          yv[n] = BNB == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
         }
       }
 #pragma unroll
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && !BNB ? 4 : 2)) void 
         av[n] = *reinterpret_cast<const uint4*>(p.add + o);
         if (BNB) {
           xv[n] = *reinterpret_cast<const uint4*>(p.bn_x + o);
-          yv[n] = p.mask_mode == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
+          yv[n] = BNB == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
         }
       }
 #pragma unroll
@@ -818,21 +833,25 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
     const int BNt = Nout > 64 ? 128 : 64;
     p.ntn = ceil_div(Nout, BNt);
     dim3 gridb(tiles_m * p.ntn);
-#define MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_)                                                            \
+#define MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_, MM_)                                                       \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
-      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, true>,         \
+      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, MM_>,          \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
       attr_set = true;                                                                                     \
     }                                                                                                      \
     const size_t ring_ = wbytes + (size_t)ST_ * (WN_ * TN_ * 32) * 128;                                    \
     const size_t epi_ = !ADD_ ? 0 : (size_t)((WN_ * TN_ * 32) == 64 ? 256 : 64) * ((WN_ * TN_ * 32) * 4 + 16); \
-    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, true>                                             \
-        <<<gridb, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                                    \
+    const size_t body_ = ((ring_ > epi_ ? ring_ : epi_) + 15) & ~(size_t)15;                               \
+    p.coef_off = (int)body_;                                                                               \
+    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, MM_>                                              \
+        <<<gridb, 64 * WM_ * WN_, body_ + 4 * (WN_ * TN_ * 32) * sizeof(float), st>>>(p);                  \
   } while (0)
-    if (BNt == 64) { if (add) MPR_WINB(4, 1, 2, 2, 4, true); else MPR_WINB(4, 1, 2, 2, 4, false); }
-    else           { if (add) MPR_WINB(4, 2, 2, 2, 2, true); else MPR_WINB(4, 2, 2, 2, 2, false); }
+#define MPR_WINB2(WM_, WN_, TM_, TN_, ST_, ADD_) do { if (p.mask_mode == 1) MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_, 1); else MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_, 2); } while (0)
+    if (BNt == 64) { if (add) MPR_WINB2(4, 1, 2, 2, 4, true); else MPR_WINB2(4, 1, 2, 2, 4, false); }
+    else           { if (add) MPR_WINB2(4, 2, 2, 2, 2, true); else MPR_WINB2(4, 2, 2, 2, 2, false); }
+#undef MPR_WINB2
 #undef MPR_WINB
     MPR_LAUNCH_CHECK("conv_win_kernel (BatchNorm-backward fusion)");
     return MPR_OK;
