@@ -251,8 +251,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
   // BatchNorm-backward fusion: the coefficients of this tile's BN channels live in LDS ([mean | invstd | scale | shift][BN],
   // behind everything the epilogue stages: registers are what keeps the second workgroup off the CU)
   float* const coef = reinterpret_cast<float*>(smem + p.coef_off);
-  if (BNB) {
-    if (tid < BN) {
+  // (the table sits inside the window / ring allocation: written only AFTER the barrier that ends every wave's main loop,
+  //  published by the barrier between the staging writes and reads)
+  auto fill_coef = [&]() {
+    if (BNB && tid < BN) {
       const int n = n0 + tid < p.Nout ? n0 + tid : 0;
       coef[tid] = p.bn_mean[n];
       coef[BN + tid] = p.bn_invstd[n];
@@ -261,8 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
         coef[3 * BN + tid] = p.bn_shift[n];
       }
     }
-    // (published by the barrier that opens the first staging pass)
-  }
+  };
   // dz = mask * q (q: the bf16-rounded gradient values), sums of dz and dz * xhat; returns the masked, re-packed group.
   // xv / yv: this group of the BatchNorm input / of the mask source, loaded by the caller (all rows at once: the loop
   // is latency-bound otherwise)
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
 #pragma unroll
     for (int ep = 0; ep < EP; ++ep) {
       win_lds_barrier();
+      if (ep == 0) fill_coef();
       const unsigned long long e0 = PROBE_NOW();
       if ((wm * TM * 32) / RPASS == ep) {
         const int wrow0 = wm * TM * 32 - ep * RPASS;
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
 #pragma unroll
     for (int ep = 0; ep < EPA; ++ep) {
       win_lds_barrier();
+      if (ep == 0) fill_coef();
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int grow = wm * (TM * 32) + i * 32;          // this 32-row m-tile inside the 256-row tile (wave-uniform)
@@ -843,10 +846,15 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
     }                                                                                                      \
     const size_t ring_ = wbytes + (size_t)ST_ * (WN_ * TN_ * 32) * 128;                                    \
     const size_t epi_ = !ADD_ ? 0 : (size_t)((WN_ * TN_ * 32) == 64 ? 256 : 64) * ((WN_ * TN_ * 32) * 4 + 16); \
-    const size_t body_ = ((ring_ > epi_ ? ring_ : epi_) + 15) & ~(size_t)15;                               \
-    p.coef_off = (int)body_;                                                                               \
-    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, MM_>                                              \
-        <<<gridb, 64 * WM_ * WN_, body_ + 4 * (WN_ * TN_ * 32) * sizeof(float), st>>>(p);                  \
+    /* coefficient table: behind what the epilogue stages (<= 36.9 KB without the skip add, 69.6 KB with it at 64    \
+       channels, 33.8 KB at 128), inside the window + ring allocation whenever that is large enough: two workgroups  \
+       of the 64-channel tile at W = 56 fill the CU's 160 KB to within 2 KB */                                       \
+    const size_t tab_ = (size_t)((ADD_ && (WN_ * TN_ * 32) == 64) ? 72 : 40) * 1024;                       \
+    const size_t need_ = tab_ + 4 * (WN_ * TN_ * 32) * sizeof(float);                                      \
+    size_t body_ = ring_ > epi_ ? ring_ : epi_;                                                            \
+    if (body_ < need_) body_ = need_;                                                                      \
+    p.coef_off = (int)tab_;                                                                                \
+    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, MM_><<<gridb, 64 * WM_ * WN_, body_, st>>>(p);    \
   } while (0)
 #define MPR_WINB2(WM_, WN_, TM_, TN_, ST_, ADD_) do { if (p.mask_mode == 1) MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_, 1); else MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_, 2); } while (0)
     if (BNt == 64) { if (add) MPR_WINB2(4, 1, 2, 2, 4, true); else MPR_WINB2(4, 1, 2, 2, 4, false); }
