@@ -77,6 +77,12 @@ int mpr_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* ad
 int mpr_conv_dgrad_add_even_supported(int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw);
 int mpr_conv_dgrad_s2(const void* dy, const void* w_dgrad, void* dx, const void* add_even, int B, int H, int W, int C,
                       int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
+/* ... + the BatchNorm backward of the block output it differentiates (relu(bn2(x2) + identity) of the PREVIOUS block):
+ * dz = gradient masked by mask_y > 0, slices [nslices][2][C] += sum dz, sum dz * xhat(bn_x); add_even may be NULL */
+int mpr_conv_dgrad_s2_bn(const void* dy, const void* w_dgrad, void* dz, const void* add_even, const void* mask_y,
+                         const void* bn_x, const float* mean, const float* invstd, float* slices, int nslices,
+                         int prezeroed, int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
+                         void* stream);
 /* dw_oihw != NULL: workspace is zeroed, filled as [K][R][S][C] and permuted into (accumulate: added to) dw_oihw.
  * dw_oihw == NULL: the gradient stays in `workspace` as [K][R][S][C] -- the memory of a channels-last weight's
  * gradient -- zeroed first unless `accumulate` (then the split-K atomics add into what is there) */

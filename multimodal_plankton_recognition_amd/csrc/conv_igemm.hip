@@ -37,6 +37,11 @@ struct ConvGemmParams {
   int par_rows, par_valid;   // stride-2 dgrad parity classes (LDS-DMA kernel): padded / real rows per class, 0 = off
   const bf16_t* add_even;    // parity classes only: [B, Pm, Qm, Nout] added at the pixels (2 h2, 2 w2) -- the data gradient
                              // of a 1x1 / stride-2 shortcut convolution, which is zero everywhere else
+  // BatchNorm-backward fusion (template BNB, data gradient of the LDS-DMA kernel): the result is the gradient w.r.t. a block
+  // output relu(bn2(x2) + identity): the epilogue applies the ReLU mask (mask_y > 0) and adds sum dz, sum dz * xhat of bn2
+  // into `stats` (slice rows) -- as conv_win.hip does for the stride-1 data gradients
+  const bf16_t *bnb_mask_y, *bnb_x;   // [M][Nout]
+  const float *bnb_mean, *bnb_invstd; // [Nout]
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {   // byte offset in a [rows][128 B] tile
@@ -265,7 +270,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // more workgroups per CU fit the 160 KB -- the loop is bound by the LATENCY of the operand stream, i.e. by the bytes
 // in flight per CU).  Swizzle keys: 128-B rows (row >> 1) & 7 over 8 chunks, 64-B rows (row >> 2) & 3
 // over 4 chunks; both make every ds_read_b128 lane group hit 16 distinct 16-B bank slots.
-template <int WM, int WN, int STAGES, bool DGRAD, int BK = 64>
+template <int WM, int WN, int STAGES, bool DGRAD, int BK = 64, bool BNB = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const ConvGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass of hipcc
   constexpr int NW = WM * WN, T = 64 * NW;
@@ -494,6 +499,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  float bmu[8], bis[8];      // BatchNorm-backward fusion: this thread's 8 channels are fixed, so are their coefficients
+  if (BNB) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = col_ok ? ncol + e : 0;
+      bmu[e] = p.bnb_mean[n];
+      bis[e] = p.bnb_invstd[n];
+    }
+  }
   if (p.dbg & 16) {      // timing experiment: no epilogue (one store keeps the accumulators alive)
     if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) p.dst[0] = (bf16_t)1.f;
     return;
@@ -544,6 +558,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
           unpack8(*reinterpret_cast<const uint4*>(p.add_even + (size_t)mc * p.Nout + ncol), g);
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] += g[e];
+        }
+        if (BNB) {
+          // dz = (mask_y > 0) * q with q the bf16-rounded gradient; sums of dz and dz * xhat
+          float q[8], ym[8], xf[8];
+          unpack8(pack8(f), q);
+          unpack8(*reinterpret_cast<const uint4*>(p.bnb_mask_y + o), ym);
+          unpack8(*reinterpret_cast<const uint4*>(p.bnb_x + o), xf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            q[e] = ym[e] > 0.f ? q[e] : 0.f;
+            s1[e] += q[e];
+            s2[e] += q[e] * (xf[e] - bmu[e]) * bis[e];
+          }
+          *reinterpret_cast<uint4*>(p.dst + o) = pack8(q);
+          continue;
         }
         const uint4 pk = pack8(f);
         *reinterpret_cast<uint4*>(p.dst + o) = pk;
@@ -856,8 +885,9 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   p.ntn = ceil_div(p.Nout, BN);
   const int gm = ceil_div(p.M, BM);
   dim3 grid(gm * p.ntn);
-  p.stat_slices = (p.stats && !dgrad) ? g_stat_slices : 0;
-  {
+  const bool bnb = dgrad && p.bnb_x != nullptr;       // (its slice rows and their zeroing: the caller's, see conv_dgrad_impl)
+  if (!bnb) {
+    p.stat_slices = (p.stats && !dgrad) ? g_stat_slices : 0;
     const bool prezeroed = mpr_conv_take_prezeroed();
     if (p.stat_slices > 0 && !prezeroed)
       MPR_HIP(hipMemsetAsync(p.stats, 0, sizeof(float) * 2 * (size_t)p.stat_slices * p.Nout, st));
@@ -885,7 +915,24 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
         <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                               \
   } while (0)
 #define MPR_DMA(WM_, WN_, ST_, BK_) do { if (dgrad) MPR_DMA5(WM_, WN_, ST_, true, BK_); else MPR_DMA5(WM_, WN_, ST_, false, BK_); } while (0)
-    if (narrow) {
+    if (bnb) {
+      // fused BatchNorm-backward epilogue: default tiles of the parity-class data gradient only
+#define MPR_DMAB(WM_, WN_, ST_)                                                                          \
+  do {                                                                                                \
+    static bool attr_set = false;                                                                     \
+    if (!attr_set) {                                                                                  \
+      hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<WM_, WN_, ST_, true, 64, true>,          \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      attr_set = true;                                                                                \
+    }                                                                                                 \
+    const size_t ring_ = (size_t)ST_ * (64 * WM_ + 64 * WN_) * 128;                                   \
+    const size_t epi_ = (size_t)64 * (64 * WN_ * 4 + 16);                                             \
+    conv_igemm_dma_kernel<WM_, WN_, ST_, true, 64, true>                                              \
+        <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                               \
+  } while (0)
+      if (narrow) MPR_DMAB(4, 1, 2); else MPR_DMAB(2, 2, 2);
+#undef MPR_DMAB
+    } else if (narrow) {
       switch (g_variant_narrow) {
         case 1: MPR_DMA(4, 1, 3, 64); break;
         case 2: MPR_DMA(2, 1, 2, 64); break;
@@ -968,6 +1015,7 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
   }
   ConvGemmParams p;
   p.src = (const bf16_t*)x; p.wpk = (const bf16_t*)w_fwd; p.dst = (bf16_t*)y; p.add = nullptr; p.add_even = nullptr; p.stats = stats;
+  p.bnb_mask_y = p.bnb_x = nullptr; p.bnb_mean = p.bnb_invstd = nullptr;
   p.sH = H; p.sW = W; p.sC = C;
   p.src_bytes = (unsigned)((size_t)B * H * W * C * 2);
   p.wpk_bytes = (unsigned)((size_t)pad_to(K, 128) * pad_to(R * S * C, 64) * 2);
@@ -992,8 +1040,16 @@ int mpr_conv_dgrad_add_even_supported(int B, int H, int W, int C, int K, int R, 
   return C % 8 == 0 && K % 8 == 0 && dgrad_parity_path(B, H, W, C, K, R, S, sh, sw) ? 1 : 0;
 }
 
+struct DgradBnb {   // BatchNorm-backward fusion of the parity-class data gradient (mask from mask_y)
+  const void *mask_y, *bn_x;
+  const float *mean, *invstd;
+  float* slices;
+  int nslices, prezeroed;
+};
+
 static int conv_dgrad_impl(const void* dy, const void* w_dgrad, void* dx, const void* add, const void* add_even, int B, int H,
-                           int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+                           int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream,
+                           const DgradBnb* bnb = nullptr) {
   MPR_REQUIRE(dy && w_dgrad && dx, "mpr_conv_dgrad: null pointer");
   MPR_REQUIRE(C % 8 == 0 && K % 8 == 0, "mpr_conv_dgrad: C (%d) and K (%d) must be multiples of 8", C, K);
   MPR_REQUIRE((sh == 1 || sh == 2) && (sw == 1 || sw == 2), "mpr_conv_dgrad: strides must be 1 or 2 (got %d,%d)", sh, sw);
@@ -1014,6 +1070,14 @@ static int conv_dgrad_impl(const void* dy, const void* w_dgrad, void* dx, const 
   p.src = (const bf16_t*)dy; p.wpk = (const bf16_t*)w_dgrad; p.dst = (bf16_t*)dx; p.add = (const bf16_t*)add;
   p.add_even = (const bf16_t*)add_even;
   p.stats = nullptr;
+  p.bnb_mask_y = p.bnb_x = nullptr; p.bnb_mean = p.bnb_invstd = nullptr;
+  if (bnb) {
+    p.bnb_mask_y = (const bf16_t*)bnb->mask_y; p.bnb_x = (const bf16_t*)bnb->bn_x;
+    p.bnb_mean = bnb->mean; p.bnb_invstd = bnb->invstd;
+    p.stats = bnb->slices; p.stat_slices = bnb->nslices;
+    if (!bnb->prezeroed)
+      MPR_HIP(hipMemsetAsync(bnb->slices, 0, sizeof(float) * 2 * (size_t)bnb->nslices * C, (hipStream_t)stream));
+  }
   p.sH = P; p.sW = Q; p.sC = K;
   p.src_bytes = (unsigned)((size_t)B * P * Q * K * 2);
   p.wpk_bytes = (unsigned)((size_t)pad_to(C, 128) * pad_to(R * S * K, 64) * 2);
@@ -1035,6 +1099,20 @@ int mpr_conv_dgrad_s2(const void* dy, const void* w_dgrad, void* dx, const void*
                       int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
   MPR_REQUIRE(add_even, "mpr_conv_dgrad_s2: null add_even");
   return conv_dgrad_impl(dy, w_dgrad, dx, nullptr, add_even, B, H, W, C, K, R, S, sh, sw, ph, pw, stream);
+}
+
+// mpr_conv_dgrad_s2 + the BatchNorm backward of the block output it differentiates, relu(bn2(x2) + identity): dz = the
+// gradient masked by mask_y > 0 (mask_y: that block output), slices [nslices][2][C] += sum dz, sum dz * xhat(bn_x) -- the
+// downsampling block's counterpart of mpr_conv_dgrad_bn (mask mode 1); add_even may be NULL.
+int mpr_conv_dgrad_s2_bn(const void* dy, const void* w_dgrad, void* dz, const void* add_even, const void* mask_y,
+                         const void* bn_x, const float* mean, const float* invstd, float* slices, int nslices, int prezeroed,
+                         int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
+  MPR_REQUIRE(mask_y && bn_x && mean && invstd && slices && nslices > 0, "mpr_conv_dgrad_s2_bn: null pointer");
+  const int P = (H + 2 * ph - R) / sh + 1, Q = (W + 2 * pw - S) / sw + 1;
+  MPR_REQUIRE(C % 8 == 0 && K % 8 == 0 && dgrad_parity_path(B, H, W, C, K, R, S, sh, sw) && P == H / 2 && Q == W / 2,
+              "mpr_conv_dgrad_s2_bn: geometry not on the parity-class path (ask mpr_conv_dgrad_add_even_supported)");
+  DgradBnb bnb = {mask_y, bn_x, mean, invstd, slices, nslices, prezeroed};
+  return conv_dgrad_impl(dy, w_dgrad, dz, nullptr, add_even, B, H, W, C, K, R, S, sh, sw, ph, pw, stream, &bnb);
 }
 
 // Is the data gradient with fused BatchNorm-backward reduction (mpr_conv_dgrad_bn) available for this geometry?

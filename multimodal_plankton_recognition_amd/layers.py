@@ -190,17 +190,21 @@ class BasicBlockFn(torch.autograd.Function):
             dxd, dgd, dbd, _ = ops.bn_bwd(dz, None, xd, gd, std, MASK_NONE, beta=bd)
             dwd = ops.conv_wgrad(x, dxd, cd, wd)
             # the shortcut conv's data gradient lives on the even pixels only: half-resolution GEMM, added by the
-            # parity-class kernel of conv1's stride-2 data gradient
-            dx = ops.conv_dgrad_shortcut(dx1, wd1, c1, x.shape, dxd, wdd, cd)
-            if dx is not None:
-                return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None
+            # parity-class kernel of conv1's stride-2 data gradient; x is the previous block's output: if that block left
+            # a note, its ReLU mask and bn2's backward sums are fused into the same epilogue
+            note = chain.take_note(x) if chain is not None else None
+            res = ops.conv_dgrad_shortcut(dx1, wd1, c1, x.shape, dxd, wdd, cd, note=note, mask_y=x)
+            if res is not None:
+                if res[1] is not None:
+                    chain.offer_sums(res[0], res[1])
+                return res[0], dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None
             skip = ops.conv_dgrad(dxd, wdd, cd, x.shape)
         else:
             dgd = dbd = dwd = None
             skip = dz
+            note = chain.take_note(x) if chain is not None else None
         # d(x) = conv1's data gradient + the skip-connection gradient (fused in the epilogue).  x is the previous block's
         # output: if that block left a note, its ReLU mask and bn2 sums are fused in as well
-        note = chain.take_note(x) if chain is not None else None
         fused0 = ops.conv_dgrad_bn(dx1, wd1, c1, x.shape, note[0], note[1], 1, mask_y=x, add=skip) if note else None
         if fused0 is not None:
             dx = fused0[0]

@@ -240,11 +240,17 @@ def conv_dgrad(dy, wd, g, x_shape, add=None):
     return dx
 
 
-def conv_dgrad_shortcut(dy, wd, g, x_shape, dy_sc, wd_sc, g_sc):
+S2_BN_FUSION = os.environ.get('MPR_S2_BN_FUSION', '1') != '0'      # (A/B: the downsampling blocks' share of the BatchNorm-backward fusion)
+
+
+def conv_dgrad_shortcut(dy, wd, g, x_shape, dy_sc, wd_sc, g_sc, note=None, mask_y=None):
     """Block-input gradient of a downsampling BasicBlock: data gradient of the stride-2 3x3 conv (dy, wd, g) + data gradient
     of the parallel 1x1 / stride-2 shortcut conv (dy_sc, wd_sc, g_sc).  The shortcut's gradient only reaches the even
     pixels: it is formed on the half-resolution grid (a plain GEMM, a quarter of the rows) and added there by the
-    parity-class kernel, instead of a full-resolution 3/4-zero map written and read back.  None: geometry not served."""
+    parity-class kernel, instead of a full-resolution 3/4-zero map written and read back.
+    `note` = (bn_x, BNState) of the BatchNorm that produced the block input (the previous block's bn2; mask_y = that
+    block's output = this block's input): the epilogue also applies the ReLU mask and leaves bn2's backward sums.
+    -> (dx, slices or None), or None when the geometry is not served."""
     if len(x_shape) != 4 or (g_sc.R, g_sc.S, g_sc.sh, g_sc.sw, g_sc.ph, g_sc.pw) != (1, 1, 2, 2, 0, 0):
         return None
     B, H, W, C = x_shape
@@ -253,8 +259,13 @@ def conv_dgrad_shortcut(dy, wd, g, x_shape, dy_sc, wd_sc, g_sc):
     half = torch.empty((B, H // 2, W // 2, C), dtype=BF16, device=dy.device)
     N.call('mpr_conv_dgrad', dy_sc, wd_sc, half, None, B, H // 2, W // 2, C, g_sc.K, 1, 1, 1, 1, 0, 0)
     dx = torch.empty(x_shape, dtype=BF16, device=dy.device)
+    if note is not None and DGRAD_BN_FUSION and S2_BN_FUSION and note[1].mean is not None and C <= 512:
+        slices, zeroed = _slice_rows(C, dy.device)
+        N.call('mpr_conv_dgrad_s2_bn', dy, wd, dx, half, mask_y, note[0], note[1].mean, note[1].invstd, slices, FIN_SLICES,
+               int(zeroed), B, H, W, C, g.K, *g.tail)
+        return dx, slices
     N.call('mpr_conv_dgrad_s2', dy, wd, dx, half, B, H, W, C, g.K, *g.tail)
-    return dx
+    return dx, None
 
 
 AUTOTUNE = os.environ.get('MPR_AUTOTUNE', '1') != '0'

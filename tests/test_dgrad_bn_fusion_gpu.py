@@ -170,8 +170,9 @@ def test_shortcut_gradient_on_the_half_resolution_grid(B, H, C, K):
     dy3 = torch.randn(B, H // 2, H // 2, K, generator=g).to(DEV).to(torch.bfloat16)
     dy1 = torch.randn(B, H // 2, H // 2, K, generator=g).to(DEV).to(torch.bfloat16)
     shape = (B, H, H, C)
-    got = ops.conv_dgrad_shortcut(dy3, wd3, g3, shape, dy1, wd1, g1)
-    assert got is not None
+    res = ops.conv_dgrad_shortcut(dy3, wd3, g3, shape, dy1, wd1, g1)
+    assert res is not None and res[1] is None
+    got = res[0]
     ref = ops.conv_dgrad(dy3, wd3, g3, shape, add=ops.conv_dgrad(dy1, wd1, g1, shape))
     assert torch.equal(got, ref)
     # and against plain fp32 arithmetic on the rounded operands
@@ -182,3 +183,35 @@ def test_shortcut_gradient_on_the_half_resolution_grid(B, H, C, K):
     want = (r3 + r1.to(torch.bfloat16).float()).permute(0, 2, 3, 1)
     err = (got.float() - want).abs().max().item()
     assert err <= 2e-2 * want.abs().max().item(), err
+
+
+@pytest.mark.parametrize('B,H,C,K', [(8, 56, 64, 128), (32, 28, 128, 256), (128, 14, 256, 512)])
+def test_downsampling_block_gradient_with_fused_bn_backward(B, H, C, K):
+    """ops.conv_dgrad_shortcut with a BatchNorm note (mpr_conv_dgrad_s2_bn): dz == the unfused gradient masked by the block
+    output's ReLU, bit for bit; the slice rows hold sum dz and sum dz * xhat."""
+    import types
+    from multimodal_plankton_recognition_amd import ops
+    g = torch.Generator().manual_seed(B + 3 * H)
+    w3 = torch.randn(K, C, 3, 3, generator=g).to(DEV) * 0.05
+    w1 = torch.randn(K, C, 1, 1, generator=g).to(DEV) * 0.1
+    g3, g1 = ops.ConvGeom((K, C, 3, 3), 2, 1), ops.ConvGeom((K, C, 1, 1), 2, 0)
+    _, wd3 = ops.packed_weights(w3, g3)
+    _, wd1 = ops.packed_weights(w1, g1)
+    dy3 = torch.randn(B, H // 2, H // 2, K, generator=g).to(DEV).to(torch.bfloat16)
+    dy1 = torch.randn(B, H // 2, H // 2, K, generator=g).to(DEV).to(torch.bfloat16)
+    shape = (B, H, H, C)
+    out_prev = torch.randn(shape, generator=g).to(DEV).to(torch.bfloat16)         # the previous block's output (mask source)
+    x2 = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(DEV).to(torch.bfloat16)  # its bn2 input
+    st = types.SimpleNamespace(mean=(torch.randn(C, generator=g) * 0.2).to(DEV), invstd=(torch.rand(C, generator=g) + 0.5).to(DEV))
+    plain, none = ops.conv_dgrad_shortcut(dy3, wd3, g3, shape, dy1, wd1, g1)
+    assert none is None
+    dz, slices = ops.conv_dgrad_shortcut(dy3, wd3, g3, shape, dy1, wd1, g1, note=(x2, st), mask_y=out_prev)
+    want = torch.where(out_prev > 0, plain, torch.zeros_like(plain))
+    assert torch.equal(dz, want)
+    s = slices.double().sum(0).cpu()                  # [2, C]
+    wz = want.double()
+    xhat = (x2.double() - st.mean.double()) * st.invstd.double()
+    ref1 = wz.sum((0, 1, 2)).cpu()
+    ref2 = (wz * xhat).sum((0, 1, 2)).cpu()
+    assert (s[0] - ref1).abs().max() <= 1e-4 * ref1.abs().max() + 1e-3
+    assert (s[1] - ref2).abs().max() <= 1e-4 * ref2.abs().max() + 1e-3
