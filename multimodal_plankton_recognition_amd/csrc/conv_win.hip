@@ -328,46 +328,52 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
       pr_ew += e1 - e0;
       // all of this thread's rows are read in one burst (unconditionally: the LDS latency is paid once, not per row),
       // the raster decode runs underneath, then the stores go out
-      constexpr int NR = RPASS / RPP;
-      uint4 pk[NR];
+      // (the fused BatchNorm-backward variant of the 8-wave tile takes its rows in two halves: with the waves of the other
+      //  pass still holding their accumulators, four rows of (tile, BatchNorm input, mask) groups do not fit 128 VGPRs)
+      constexpr int NSUB = (BNB && T == 512) ? 2 : 1;
+      constexpr int NR = RPASS / RPP / NSUB;
 #pragma unroll
-      for (int n = 0; n < NR; ++n) pk[n] = *reinterpret_cast<const uint4*>(smem + (rr + n * RPP) * RS + ch * 16);
-      uint32_t pix[NR];
+      for (int sub = 0; sub < NSUB; ++sub) {
+        uint4 pk[NR];
 #pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        const int G = G0 + ep * RPASS + rr + n * RPP;
-        const uint32_t Gc = G < p.Gtot ? G : 0;
-        const uint32_t b = fdiv(Gc, p.div_img);
-        const uint32_t pp = Gc - b * p.img;
-        const uint32_t hh = fdiv(pp, p.div_wp);
-        const uint32_t ww = pp - hh * p.Wp;
-        const bool ok = col_ok && G < p.Gtot && hh < (uint32_t)p.H && ww < (uint32_t)p.W;
-        pix[n] = ok ? (b * p.H + hh) * p.W + ww : 0xFFFFFFFFu;
-      }
-      uint4 xv[BNB ? NR : 1], yv[BNB ? NR : 1];
-      if (BNB) {
+        for (int n = 0; n < NR; ++n) pk[n] = *reinterpret_cast<const uint4*>(smem + (rr + (sub * NR + n) * RPP) * RS + ch * 16);
+        uint32_t pix[NR];
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
-          const size_t o = (size_t)(pix[n] != 0xFFFFFFFFu ? pix[n] : 0u) * p.Nout + (col_ok ? ncol : 0);
-          xv[n] = *reinterpret_cast<const uint4*>(p.bn_x + o);
-          yv[n] = BNB == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
+          const int G = G0 + ep * RPASS + rr + (sub * NR + n) * RPP;
+          const uint32_t Gc = G < p.Gtot ? G : 0;
+          const uint32_t b = fdiv(Gc, p.div_img);
+          const uint32_t pp = Gc - b * p.img;
+          const uint32_t hh = fdiv(pp, p.div_wp);
+          const uint32_t ww = pp - hh * p.Wp;
+          const bool ok = col_ok && G < p.Gtot && hh < (uint32_t)p.H && ww < (uint32_t)p.W;
+          pix[n] = ok ? (b * p.H + hh) * p.W + ww : 0xFFFFFFFFu;
         }
-      }
+        uint4 xv[BNB ? NR : 1], yv[BNB ? NR : 1];
+        if (BNB) {
 #pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        if (pix[n] != 0xFFFFFFFFu) {
-          const size_t o = (size_t)pix[n] * p.Nout + ncol;
-          if (BNB) {
-            float q[8];
-            unpack8(pk[n], q);
-            *reinterpret_cast<uint4*>(p.dst + o) = bnb_group(q, xv[n], yv[n]);
-          } else {
-            *reinterpret_cast<uint4*>(p.dst + o) = pk[n];
-            if (p.stats) {
+          for (int n = 0; n < NR; ++n) {
+            const size_t o = (size_t)(pix[n] != 0xFFFFFFFFu ? pix[n] : 0u) * p.Nout + (col_ok ? ncol : 0);
+            xv[n] = *reinterpret_cast<const uint4*>(p.bn_x + o);
+            yv[n] = BNB == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          if (pix[n] != 0xFFFFFFFFu) {
+            const size_t o = (size_t)pix[n] * p.Nout + ncol;
+            if (BNB) {
               float q[8];
               unpack8(pk[n], q);
+              *reinterpret_cast<uint4*>(p.dst + o) = bnb_group(q, xv[n], yv[n]);
+            } else {
+              *reinterpret_cast<uint4*>(p.dst + o) = pk[n];
+              if (p.stats) {
+                float q[8];
+                unpack8(pk[n], q);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+                for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+              }
             }
           }
         }
@@ -403,55 +409,59 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
         }
       }
       win_lds_barrier();
-      constexpr int NRA = RPA / RPP;
+      constexpr int NSUBA = (BNB && T == 512) ? 2 : 1;      // (as above: 128 VGPRs)
+      constexpr int NRA = RPA / RPP / NSUBA;
       // raster decode of all of this thread's rows, then ALL their global loads (residual, BatchNorm input, mask) in one
       // burst, then the LDS reads and the arithmetic: one exposed latency per pass instead of one per row
-      uint32_t pixa[NRA];
 #pragma unroll
-      for (int n = 0; n < NRA; ++n) {
-        const int G = G0 + ep * RPA + rr + n * RPP;
-        const uint32_t Gc = G < p.Gtot ? G : 0;
-        const uint32_t b = fdiv(Gc, p.div_img);
-        const uint32_t pp = Gc - b * p.img;
-        const uint32_t hh = fdiv(pp, p.div_wp);
-        const uint32_t ww = pp - hh * p.Wp;
-        const bool ok = col_ok && G < p.Gtot && hh < (uint32_t)p.H && ww < (uint32_t)p.W;
-        pixa[n] = ok ? (b * p.H + hh) * p.W + ww : 0xFFFFFFFFu;
-      }
-      uint4 av[NRA], xv[BNB ? NRA : 1], yv[BNB ? NRA : 1];
+      for (int sub = 0; sub < NSUBA; ++sub) {
+        uint32_t pixa[NRA];
 #pragma unroll
-      for (int n = 0; n < NRA; ++n) {
-        const size_t o = (size_t)(pixa[n] != 0xFFFFFFFFu ? pixa[n] : 0u) * p.Nout + (col_ok ? ncol : 0);
-        av[n] = *reinterpret_cast<const uint4*>(p.add + o);
-        if (BNB) {
-          xv[n] = *reinterpret_cast<const uint4*>(p.bn_x + o);
-          yv[n] = BNB == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
+        for (int n = 0; n < NRA; ++n) {
+          const int G = G0 + ep * RPA + rr + (sub * NRA + n) * RPP;
+          const uint32_t Gc = G < p.Gtot ? G : 0;
+          const uint32_t b = fdiv(Gc, p.div_img);
+          const uint32_t pp = Gc - b * p.img;
+          const uint32_t hh = fdiv(pp, p.div_wp);
+          const uint32_t ww = pp - hh * p.Wp;
+          const bool ok = col_ok && G < p.Gtot && hh < (uint32_t)p.H && ww < (uint32_t)p.W;
+          pixa[n] = ok ? (b * p.H + hh) * p.W + ww : 0xFFFFFFFFu;
         }
-      }
+        uint4 av[NRA], xv[BNB ? NRA : 1], yv[BNB ? NRA : 1];
 #pragma unroll
-      for (int n = 0; n < NRA; ++n) {
-        if (pixa[n] != 0xFFFFFFFFu) {
-          const int r = rr + n * RPP;
-          const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
-          const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
-          float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          const size_t o = (size_t)pixa[n] * p.Nout + ncol;
-          float g[8];
-          unpack8(av[n], g);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += g[e];
-          const uint4 pk = pack8(f);
+        for (int n = 0; n < NRA; ++n) {
+          const size_t o = (size_t)(pixa[n] != 0xFFFFFFFFu ? pixa[n] : 0u) * p.Nout + (col_ok ? ncol : 0);
+          av[n] = *reinterpret_cast<const uint4*>(p.add + o);
           if (BNB) {
-            float q[8];
-            unpack8(pk, q);
-            *reinterpret_cast<uint4*>(p.dst + o) = bnb_group(q, xv[n], yv[n]);
-          } else {
-            *reinterpret_cast<uint4*>(p.dst + o) = pk;
-            if (p.stats) {
+            xv[n] = *reinterpret_cast<const uint4*>(p.bn_x + o);
+            yv[n] = BNB == 1 ? *reinterpret_cast<const uint4*>(p.mask_y + o) : make_uint4(0, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NRA; ++n) {
+          if (pixa[n] != 0xFFFFFFFFu) {
+            const int r = rr + (sub * NRA + n) * RPP;
+            const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
+            const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
+            float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const size_t o = (size_t)pixa[n] * p.Nout + ncol;
+            float g[8];
+            unpack8(av[n], g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+            const uint4 pk = pack8(f);
+            if (BNB) {
               float q[8];
               unpack8(pk, q);
+              *reinterpret_cast<uint4*>(p.dst + o) = bnb_group(q, xv[n], yv[n]);
+            } else {
+              *reinterpret_cast<uint4*>(p.dst + o) = pk;
+              if (p.stats) {
+                float q[8];
+                unpack8(pk, q);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+                for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+              }
             }
           }
         }
