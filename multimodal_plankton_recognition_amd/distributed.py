@@ -236,8 +236,11 @@ class GradBuckets:
     behind the streams that write it -- the weight-gradient side stream and, through an event, the backward stream -- on
     RCCL's own stream, so it runs underneath the remaining data-gradient chain.  ResNet-18's layer4 alone is 75 % of the
     gradient bytes and the FIRST thing backward finishes: its 33.6 MB cross xGMI while layers 3..1 are still computing.
-    Buckets that are not complete when backward ends (parameters of the second encoder stream, parameters without a
-    gradient this step) are reduced in finish(), after every gradient stream has been joined.  Without overlap support
+    Every bucket remembers the compute streams its parameters reported on (the two encoders run on different streams, each
+    with its own weight-gradient side stream) and its collective waits for exactly those.  Complete buckets without a later
+    report (the branch enqueued last) are launched at the top of finish(), still asynchronously; buckets that are not
+    complete when backward ends (parameters without a gradient this step) are reduced after every gradient stream has
+    been joined.  Without overlap support
     (gloo rehearsal) everything happens in finish()."""
 
     def __init__(self, opt, comm, groups):
@@ -261,7 +264,7 @@ class GradBuckets:
         rest = sorted((o, n) for i, (o, n) in opt.offsets.items() if i not in covered)
         self.rest = self._runs(rest)
         self.owner = {i: k for k, b in enumerate(self.buckets) for i in b[3]}
-        self.count, self.sent, self.works, self.pending = [], [], [], []
+        self.count, self.sent, self.works, self.pending, self.streams = [], [], [], [], []
         self._observer = self._on_ready
         self.active = False
 
@@ -279,6 +282,7 @@ class GradBuckets:
     def begin(self):
         self.count = [set() for _ in self.buckets]
         self.sent = [False] * len(self.buckets)
+        self.streams = [{} for _ in self.buckets]      # per bucket: the compute streams its gradient kernels were enqueued on
         self.works, self.pending = [], []
         self.active = True
         if self._observer not in ops.grad_ready_observers:
@@ -299,26 +303,40 @@ class GradBuckets:
         if k is None or self.sent[k]:
             return
         self.count[k].add(id(param))
+        if self.comm.overlaps:
+            cur = torch.cuda.current_stream()          # (autograd runs a node on the stream of its forward: the two encoders
+            self.streams[k][cur.cuda_stream] = cur     #  differ, and each has its own weight-gradient side stream)
         if len(self.count[k]) == self.buckets[k][2] and k not in self.pending:
             self.pending.append(k)
 
     def _launch(self, k):
         lo, hi = self.buckets[k][0], self.buckets[k][1]
-        cur = torch.cuda.current_stream()
-        side = ops.wgrad_side_stream_of(cur)
-        if side is not None:
-            # weight gradients of this bucket are queued on the side stream, everything else on the backward stream:
-            # the collective goes behind both (the side stream waits for an event of the backward stream -- it lags anyway)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                self.works.append(self.comm.all_reduce_sum_async(self.opt.flat_grad[lo:hi]))
-        else:
+        srcs = list(self.streams[k].values()) or [torch.cuda.current_stream()]
+        # The bucket's gradients were written on `srcs` (the backward streams of the Functions that own its parameters) and on
+        # their weight-gradient side streams: the collective goes behind ALL of them, carried by one of the side streams
+        # (which lags anyway) so that the data-gradient chain itself never waits for RCCL.
+        carrier = ops.wgrad_side_stream_of(srcs[-1]) or srcs[-1]
+        for s in srcs:
+            if s is not carrier:
+                carrier.wait_stream(s)
+            sd = ops.wgrad_side_stream_of(s)
+            if sd is not None and sd is not carrier:
+                carrier.wait_stream(sd)
+        with torch.cuda.stream(carrier):
             self.works.append(self.comm.all_reduce_sum_async(self.opt.flat_grad[lo:hi]))
         self.sent[k] = True
 
     def finish(self):
         """After backward: join the gradient streams, reduce what is left, wait for what is in flight."""
         self.active = False
+        if self.comm.overlaps:
+            # complete buckets nobody launched (the branch the host enqueued LAST -- the profile encoder: autograd walks the
+            # image branch first -- has no later report to trigger it): still asynchronous, each behind its own streams only,
+            # BEFORE the join below makes this stream wait for everything.  The profile branch is done on the GPU a few
+            # milliseconds before the image chain: its gradients cross the links underneath that chain.
+            for k, b in enumerate(self.buckets):
+                if not self.sent[k] and len(self.count[k]) == b[2]:
+                    self._launch(k)
         self.pending = []
         ops.join_gradient_streams()
         g = self.opt.flat_grad
@@ -337,13 +355,21 @@ class GradBuckets:
 
 
 def default_bucket_groups(model):
-    """Image backbone back to front in three buckets (layer4 | layer3 | layer2 + layer1 + stem); the rest of the model
-    (projections, profile encoder, loss) is reduced after backward."""
+    """Buckets in the order backward completes them: layer4 (+ the image projection, next to it in the buffer: 75 % of the
+    gradient bytes, done first) | layer3 | the profile branch (its own stream: done ~a quarter into the image branch's
+    backward) | layer2 | layer1 + stem -- only that last one, 0.65 MB at ResNet-18, is reduced after backward has ended.
+    Whatever is left over (the loss's scalars) is reduced in finish()."""
     bb = getattr(getattr(model, 'image_encoder', None), 'backbone', None)
     if bb is None or not hasattr(bb, 'layer4'):
         return []
-    early = [p for n, p in bb.named_parameters() if not n.startswith(('layer3.', 'layer4.'))]
-    return [list(bb.layer4.parameters()), list(bb.layer3.parameters()), early]
+    groups = [list(bb.layer4.parameters()) + [p for p in getattr(model, 'image_projection', torch.nn.Module()).parameters()],
+              list(bb.layer3.parameters())]
+    prof = [p for n in ('profile_encoder', 'profile_projection') for p in getattr(model, n, torch.nn.Module()).parameters()]
+    if prof:
+        groups.append(prof)
+    groups.append(list(bb.layer2.parameters()))
+    groups.append([p for n, p in bb.named_parameters() if not n.startswith(('layer2.', 'layer3.', 'layer4.'))])
+    return groups
 
 
 # ------------------------------------------------------------------------------------------------ DP step
@@ -369,7 +395,11 @@ class DataParallelStep:
         self._views = None
         self.buckets = None
         if hasattr(optimizer, 'flat_grad') and os.environ.get('MPR_DP_BUCKETS', '1') != '0':
-            self.buckets = GradBuckets(optimizer, self.comm, default_bucket_groups(model))
+            try:
+                self.buckets = GradBuckets(optimizer, self.comm, default_bucket_groups(model))
+            except ValueError:       # a model whose parameter order splits a group: backbone stages only
+                bb = model.image_encoder.backbone
+                self.buckets = GradBuckets(optimizer, self.comm, [list(bb.layer4.parameters()), list(bb.layer3.parameters())])
 
     def _flat_views(self):
         if self._flat is None:
