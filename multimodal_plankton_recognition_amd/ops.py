@@ -303,13 +303,18 @@ USE_WGRAD_SCRATCH = os.environ.get('MPR_WGRAD_SCRATCH', '1') != '0'
 
 def _tune_wgrad(x, dy, g, key):
     """First use of a large geometry: time the weight-gradient kernels -- the sliding-window kernel (3x3 stride 1 only)
-    and the gather kernel, each at a few workgroup-count targets of the split over pixels (occupancy rounds vs. atomic
-    traffic vs. L2 sharing differ shape by shape) -- on scratch output, and keep the fastest (window?, target)."""
+    and the gather kernel, each at a few workgroup-count targets of the split over pixels -- on scratch output, and keep
+    the candidate with the smallest CU-TIME: time alone x the share of the chip its workgroups hold (one window workgroup
+    or two gather workgroups fill a CU: their registers leave no room for anything else on it).  Inside the step the weight
+    gradients run beside the data-gradient chain, which takes whatever CUs they leave: a launch on 160 CUs that runs 30 %
+    longer costs the step LESS than one that holds all 256 (in-process A/B on C3: fixed targets of 160 / 192 workgroups
+    10.37 / 10.40 ms per step, 256: 10.55, the alone-fastest choice per shape: 10.66)."""
     B, H, W, C = _geom(x)
     ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
     win_ok = (g.R, g.S, g.sh, g.sw, g.ph, g.pw) == (3, 3, 1, 1, 1, 1)
-    cands = ([(1, 256), (1, 512)] if win_ok else []) + [(0, 256), (0, 512), (0, 768), (0, 1024)]
-    best, best_t = (0, 768), None
+    cands = ([(1, 128), (1, 160), (1, 192), (1, 256), (1, 512)] if win_ok else []) + \
+            [(0, 256), (0, 384), (0, 512), (0, 768), (0, 1024)]
+    best, best_s = (0, 768), None
     old_win = N.query('mpr_conv_set_wgrad_window', 1)
     for win, tg in cands:
         N.query('mpr_conv_set_wgrad_window', win)
@@ -321,9 +326,10 @@ def _tune_wgrad(x, dy, g, key):
             _wgrad_call(x, dy, ws, None, 1, B, H, W, C, g.K, *g.tail)
         b.record()
         b.synchronize()
-        t = a.elapsed_time(b)
-        if best_t is None or t < best_t:
-            best, best_t = (win, tg), t
+        slots = 256 if win else 512
+        score = a.elapsed_time(b) * min(tg, slots) / slots
+        if best_s is None or score < best_s:
+            best, best_s = (win, tg), score
     N.query('mpr_conv_set_wgrad_window', old_win)
     _wgrad_split[key] = best
     if _WGRAD_PLAN:
