@@ -59,7 +59,8 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   static_assert(KH * PS <= 2, "twelve waves at most");
   constexpr int NW = 6 * KH * PS;
   constexpr int CHUNK = 64 * PS * PB;          // pixels per chunk
-  constexpr int RING = CHUNK == 64 ? 256 : 512;   // x ring rows (128 B each: 64 channels): 2 chunks + both halos, power of two
+  constexpr int RING = 512;                    // x ring rows (128 B each: 64 channels): 3 chunks + both halos (<= 512), power of two
+  constexpr int NST = 3;                       // dy stages: chunk ci + 2 is in flight while chunk ci is multiplied
   constexpr int XBYTES = RING * 128;
   constexpr int DROW = 128 * KH;               // dy stage row bytes (64*KH output channels)
   constexpr int DSTAGE = CHUNK * DROW;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   constexpr int XI_IT = (CHUNK / 8 + 16 + NW - 1) / NW;    // initial window: up to CHUNK + 2*64 rows
   constexpr int XC_IT = (CHUNK / 8 + NW - 1) / NW;         // per chunk: CHUNK new rows
   auto ring = [](int G) -> int { return G & (RING - 1); };
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [x ring 32 KB][dy stage 0][dy stage 1]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [x ring 64 KB][dy stage 0][dy stage 1][dy stage 2]
   unsigned char* const dyst = smem + XBYTES;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address of smem
 
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
         rs_x, (__attribute__((address_space(3))) void*)(smem + ring(G8) * 128), 16, v, 0, 0, 0);
   };
   auto issue_x8 = [&](int G8) { fire_x8(G8, x_off(G8)); };
-  // dy rows of chunk ci -> stage ci & 1: instruction I covers 1024 / DROW rows
+  // dy rows of chunk ci -> stage ci % NST: instruction I covers 1024 / DROW rows
   auto dy_off = [&](int ci, int I) -> uint32_t {
     constexpr int CH = DROW / 16;                       // 16-B chunks per row (8 or 16)
     const int q = I * 64 + lane;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   };
   auto fire_chunk = [&](int ci) {
     const int lo = ci * CHUNK + p.halo8;
-    unsigned char* st = dyst + (ci & 1) * DSTAGE;
+    unsigned char* st = dyst + (ci % NST) * DSTAGE;
 #pragma unroll
     for (int j = 0; j < XC_IT; ++j) {
       const int I = wid + j * NW;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
     }
     prep_chunk(c0);          // (only its dy half is used: the window above already holds chunk c0's rows)
     {
-      unsigned char* st = dyst + (c0 & 1) * DSTAGE;
+      unsigned char* st = dyst + (c0 % NST) * DSTAGE;
 #pragma unroll
       for (int j = 0; j < D_IT; ++j) {
         const int I = wid + j * NW;
@@ -198,26 +199,27 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
                                                    0, 0, 0);
       }
     }
-    if (c0 + 1 < c1) prep_chunk(c0 + 1);
+    // two chunks of look-ahead: chunk c0 + 1 goes out here, the offsets of c0 + 2 are prepared for the first iteration
+    if (c0 + 1 < c1) {
+      prep_chunk(c0 + 1);
+      fire_chunk(c0 + 1);
+    }
+    if (c0 + 2 < c1) prep_chunk(c0 + 2);
+    wgw_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   }
   unsigned long long pr_wait = 0, pr_bar = 0, pr_comp = 0, pr_iss = 0;
 #define WGW_NOW() (p.probe ? __builtin_readcyclecounter() : 0ull)
   const unsigned long long pr_t0 = WGW_NOW();
+  // Loop invariant at the top of iteration ci: chunk ci's operands are in LDS for EVERY wave (confirmed by the previous
+  // barrier), chunk ci + 1's are in flight (issued one iteration ago).  So the first fragment reads of chunk ci go out
+  // BEFORE this iteration's wait + barrier -- which only confirm chunk ci + 1 and release the stage / ring rows that chunk
+  // ci + 2 overwrites (last read in iteration ci - 1) -- and the matrix pipe is not drained at every chunk boundary: with a
+  // two-stage ring the barrier sat between the DMA wait and the first LDS read, ~1100 idle cycles per 2300-cycle chunk.
   for (int ci = c0; ci < c1; ++ci) {
-    const unsigned long long q0 = WGW_NOW();
-    wgw_wait_vmcnt<0>();
-    const unsigned long long q1 = WGW_NOW();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const unsigned long long q2 = WGW_NOW();
-    pr_wait += q1 - q0;
-    pr_bar += q2 - q1;
-    // next chunk: 64 new ring rows at the leading edge + its dy (both buffers were last read one barrier ago)
-    if (ci + 1 < c1) fire_chunk(ci + 1);
-    const unsigned long long q3 = WGW_NOW();
-    pr_iss += q3 - q2;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const uint32_t da = lds0 + XBYTES + (ci & 1) * DSTAGE;
+    const uint32_t da = lds0 + XBYTES + (ci % NST) * DSTAGE;
     // software-pipelined k-steps: wait for the fragments of step ks, put the reads of step ks+1 in flight, then the
     // six MFMAs of step ks
     s16x4 ra[2][2][2], rb[2][3][2];      // [buffer][tile][half]
@@ -239,6 +241,18 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
       }
     };
     issue_reads(0, 0);
+    const unsigned long long q0 = WGW_NOW();
+    wgw_wait_vmcnt<0>();
+    const unsigned long long q1 = WGW_NOW();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned long long q2 = WGW_NOW();
+    pr_wait += q1 - q0;
+    pr_bar += q2 - q1;
+    // chunk ci + 2: its new ring rows at the leading edge + its dy (stage and rows were last read in iteration ci - 1)
+    if (ci + 2 < c1) fire_chunk(ci + 2);
+    const unsigned long long q3 = WGW_NOW();
+    pr_iss += q3 - q2;
 #pragma unroll
     for (int ks = 0; ks < 4 * PB; ++ks) {
       const int cur = ks & 1;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
         for (int s = 0; s < 3; ++s)
           acc[i][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[s], acc[i][s], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (ks == 1 && ci + 2 < c1) prep_chunk(ci + 2);      // address arithmetic underneath the MFMAs just issued
+      if (ks == 1 && ci + 3 < c1) prep_chunk(ci + 3);      // address arithmetic underneath the MFMAs just issued
     }
     pr_comp += WGW_NOW() - q3;
   }
@@ -410,7 +424,7 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   // partial slices instead of atomics when the caller lent enough scratch for THIS launch (one-shot)
   p.part = (scratch && (long long)nsplit * K * p.Ng <= scratch_floats) ? scratch : nullptr;
   const dim3 grid(nsplit * tiles);
-  const size_t lds = PS * PB == 2 ? (size_t)512 * 128 + 2 * 128 * 128 * (size_t)KH : 256 * 128 + 2 * 64 * 128 * (size_t)KH;
+  const size_t lds = (size_t)512 * 128 + 3 * (size_t)(64 * PS * PB) * 128 * KH;      // x ring + three dy stages
   if (PB == 2) {
     static bool attr_set = false;
     if (!attr_set) {
