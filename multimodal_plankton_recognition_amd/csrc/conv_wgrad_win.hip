@@ -256,6 +256,9 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
 #pragma unroll
     for (int ks = 0; ks < 4 * PB; ++ks) {
       const int cur = ks & 1;
+      // (per-wave probe, scripts/wgw_probe_waves.py: the three waves of a SIMD are served oldest first -- 2196 / 2491 / 2818
+      //  cycles of "compute" per chunk, barrier waits 820 / 460 / 96 -- and the youngest runs its last k-steps alone at
+      //  LDS-latency pace: ~900 of the 3200 cycles per chunk.  Rotating s_setprio per k-step made it worse: 3700.)
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(ra[cur][0][0]), "+v"(ra[cur][0][1]), "+v"(ra[cur][1][0]), "+v"(ra[cur][1][1]),
                      "+v"(rb[cur][0][0]), "+v"(rb[cur][0][1]), "+v"(rb[cur][1][0]), "+v"(rb[cur][1][1]),
@@ -281,6 +284,10 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
     }
     pr_comp += WGW_NOW() - q3;
   }
+  if (p.probe && (p.dbg & 2) && lane == 0) {      // per-wave probe: 16 x 8 uint64 per workgroup (mpr_conv_set_wgrad_window(1 | 2 << 8))
+    unsigned long long* o = p.probe + ((size_t)blockIdx.x * 16 + wid) * 8;
+    o[0] = WGW_NOW() - pr_t0; o[1] = pr_wait; o[2] = pr_bar; o[3] = pr_iss; o[4] = pr_comp; o[5] = (unsigned long long)(c1 - c0);
+  } else
   if (p.probe && tid == 0) {
     unsigned long long* o = p.probe + (size_t)blockIdx.x * 8;
     o[0] = WGW_NOW() - pr_t0; o[1] = pr_wait; o[2] = pr_bar; o[3] = pr_iss; o[4] = pr_comp; o[5] = (unsigned long long)(c1 - c0);
