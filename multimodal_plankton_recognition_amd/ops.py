@@ -90,6 +90,21 @@ class _PackRegistry:
     def __init__(self):
         self.entries = []        # [weakref(weight), data_ptr, wf, wd, geom]
         self.table = None
+        # The refresh runs on its own stream behind the optimizer step; a stream that is about to READ panels waits for it
+        # once (packed_weights -> ready()).  The ResNet stem reads no panel (the fused stem builds its own from the fp32
+        # filter), so the 55-us refresh sits underneath the stem's first kernels instead of in front of them.
+        self.stream = None
+        self.event = None
+        self.gen = 0
+        self.seen = {}           # raw stream handle -> generation it has waited for
+
+    def ready(self, dev):
+        if self.event is None:
+            return
+        h = torch._C._cuda_getCurrentRawStream(dev)
+        if self.seen.get(h) != self.gen:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.seen[h] = self.gen
 
     def add(self, weight, wf, wd, geom):
         import weakref
@@ -107,12 +122,24 @@ class _PackRegistry:
             rows = [[e[1], e[2].data_ptr(), e[3].data_ptr() if e[3] is not None else 0, e[4].K, e[4].C, e[4].R, e[4].S,
                      *_kcrs_strides(e[0]()), 0] for e in live]
             self.table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(live[0][2].device, non_blocking=True)
-        N.call('mpr_conv_pack_weights_multi', self.table, len(live))
+        if OVERLAP_REPACK:
+            cur = torch.cuda.current_stream()
+            if self.stream is None:
+                self.stream = torch.cuda.Stream()
+                self.event = torch.cuda.Event()
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                N.call('mpr_conv_pack_weights_multi', self.table, len(live))
+                self.event.record(self.stream)
+            self.gen += 1
+        else:
+            N.call('mpr_conv_pack_weights_multi', self.table, len(live))
         for e in live:
             w = e[0]()
             w._mpr_packed = ((w.data_ptr(), w._version), e[2], e[3])
 
 
+OVERLAP_REPACK = os.environ.get('MPR_OVERLAP_REPACK', '1') != '0'
 pack_registry = _PackRegistry()
 
 
@@ -121,6 +148,7 @@ def packed_weights(weight, geom, need_dgrad=True):
     # the cache entry lives ON the tensor object (dies with it: no id()/address aliasing between tensors)
     key = (weight.data_ptr(), weight._version)
     hit = getattr(weight, '_mpr_packed', None)
+    pack_registry.ready(weight.device.index)
     if hit is not None and hit[0] == key and (hit[2] is not None or not need_dgrad):
         return hit[1], hit[2]
     nf = (geom.K + 127) // 128 * 128 * ((geom.R * geom.S * geom.C + 63) // 64 * 64)
