@@ -502,6 +502,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// LDS staging accesses as INLINE ASM: hipcc guards every LDS access it cannot prove disjoint from an LDS-DMA in flight with
+// s_waitcnt vmcnt(0) -- in the persistent kernel that was the epilogue's first staging write waiting for the WHOLE window of
+// the next tile, issued a moment earlier precisely to land underneath that epilogue (per-tile probe: epilogue 12.5 K of
+// 27 K cycles).  The staging slices and the window are disjoint by construction; completion is the s_waitcnt lgkmcnt(0)
+// the code already carries.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ void win_lds_write_b64(uint32_t addr, u32x2_t v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4_t win_lds_read_b128(uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
 // Persistent form of the 256 x 64 tile (N <= 64: ResNet layer1, whose 9-chunk loop is shorter than the tile's own
 // prologue + epilogue).  One workgroup per (CU, slot) walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...:
 //   * the NEXT tile's window DMA is issued as soon as the loop of the current tile ends -- it lands underneath the
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
 //   * BatchNorm partial sums stay in registers over all tiles of the workgroup: gridDim.x partial rows per conv.
 // LDS: window | 2 x 8 KB weight stages | 4 x 4 KB staging  (<= 80 KB: two workgroups per CU).
 template <bool DGRAD>
-__global__ __launch_bounds__(256) void conv_win_persist_kernel(const WinParams p) {
+__global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParams p) {      // (two workgroups per CU: <= 256 VGPRs)
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = 4, BM = 256, BN = 64, TM = 2, TN = 2;
   constexpr int WI_MAX = (BM + 2 * 58 + 7) / 8, WIW = (WI_MAX + NW - 1) / NW;
@@ -526,6 +542,7 @@ __global__ __launch_bounds__(256) void conv_win_persist_kernel(const WinParams p
   const int wrows8 = (p.wrows + 7) & ~7;
   unsigned char* const bring = smem + wrows8 * 128;
   unsigned char* const stage = bring + 2 * BSTAGE + wid * 4096;      // this wave's private 32 x 128 B
+  const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)stage;
   const int ntiles = (p.Gtot + BM - 1) / BM;
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
@@ -598,6 +615,10 @@ __global__ __launch_bounds__(256) void conv_win_persist_kernel(const WinParams p
 
   const int nk = 9 * p.ncb;
   int gk = 0;                                   // chunks done by this workgroup (weight ring position)
+  // (timing probe, wave 0: cycles waiting for DMA / at the chunk barrier / in the MFMA steps / in the epilogue; tiles)
+  unsigned long long pq_wait = 0, pq_bar = 0, pq_comp = 0, pq_epi = 0, pq_tiles = 0;
+#define PQ_NOW() (p.probe ? __builtin_readcyclecounter() : 0ull)
+  const unsigned long long pq_t0 = PQ_NOW();
   int tile = blockIdx.x;
   if (tile < ntiles) {
     decode_window(tile * BM);
@@ -621,9 +642,14 @@ __global__ __launch_bounds__(256) void conv_win_persist_kernel(const WinParams p
         asm volatile("" ::: "memory");
         issue_window(cb);
       }
+      const unsigned long long pq0 = PQ_NOW();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long pq1 = PQ_NOW();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      const unsigned long long pq2 = PQ_NOW();
+      pq_wait += pq1 - pq0;
+      pq_bar += pq2 - pq1;
       const int d = DGRAD ? (1 - tr) * p.Wp + (1 - ts) : (tr - 1) * p.Wp + (ts - 1);
       const int rowA = baseA + d;
       const int key = (rowA >> 1) & 7;
@@ -662,7 +688,9 @@ __global__ __launch_bounds__(256) void conv_win_persist_kernel(const WinParams p
       }
       if (++ts == 3) { ts = 0; ++tr; }
       if (++tap == 9) { tap = 0; tr = 0; ++cb; }
+      pq_comp += PQ_NOW() - pq2;
     }
+    const unsigned long long pq3 = PQ_NOW();
     // every wave is done with this tile's window: the next tile's goes out now and lands underneath the epilogue
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -677,18 +705,22 @@ __global__ __launch_bounds__(256) void conv_win_persist_kernel(const WinParams p
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          uint2 v;
+          u32x2_t v;
           v.x = pack_bf16x2(acc[j][i][4 * g], acc[j][i][4 * g + 1]);
           v.y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
-          *reinterpret_cast<uint2*>(stage + frow * 128 + (((4 * j + g) ^ (frow & 7)) << 4) + fh * 8) = v;
+          win_lds_write_b64(stage_lds + frow * 128 + (((4 * j + g) ^ (frow & 7)) << 4) + fh * 8, v);
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private: no barrier
-      uint4 pk[4];
+      u32x4_t pkv[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int r = erow + 8 * it;
-        pk[it] = *reinterpret_cast<const uint4*>(stage + r * 128 + ((ech ^ (r & 7)) << 4));
+        pkv[it] = win_lds_read_b128(stage_lds + r * 128 + ((ech ^ (r & 7)) << 4));
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pkv[0]), "+v"(pkv[1]), "+v"(pkv[2]), "+v"(pkv[3])::"memory");
+      uint4 pk[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) pk[it] = make_uint4(pkv[it].x, pkv[it].y, pkv[it].z, pkv[it].w);
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int G = G0 + wm * 64 + i * 32 + erow + 8 * it;
@@ -709,7 +741,14 @@ __global__ __launch_bounds__(256) void conv_win_persist_kernel(const WinParams p
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the slice is rewritten
     }
+    pq_epi += PQ_NOW() - pq3;
+    ++pq_tiles;
   }
+  if (p.probe && tid == 0) {
+    unsigned long long* o = p.probe + (size_t)blockIdx.x * 16;
+    o[0] = PQ_NOW() - pq_t0; o[1] = pq_wait; o[2] = pq_bar; o[3] = pq_comp; o[4] = pq_epi; o[5] = pq_tiles;
+  }
+#undef PQ_NOW
   if (p.stats) {
     // one partial row per workgroup: [T][16 (+1)] -> 8 channel groups x 16 values, 32 threads each
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
