@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParam
   const int nk = 9 * p.ncb;
   int gk = 0;                                   // chunks done by this workgroup (weight ring position)
   // (timing probe, wave 0: cycles waiting for DMA / at the chunk barrier / in the MFMA steps / in the epilogue; tiles)
-  unsigned long long pq_wait = 0, pq_bar = 0, pq_comp = 0, pq_epi = 0, pq_tiles = 0;
+  unsigned long long pq_wait = 0, pq_bar = 0, pq_comp = 0, pq_epi = 0, pq_tiles = 0, pq_e1 = 0, pq_e2 = 0, pq_e3 = 0;
 #define PQ_NOW() (p.probe ? __builtin_readcyclecounter() : 0ull)
   const unsigned long long pq_t0 = PQ_NOW();
   int tile = blockIdx.x;
@@ -688,6 +688,10 @@ __global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParam
       }
       if (++ts == 3) { ts = 0; ++tr; }
       if (++tap == 9) { tap = 0; tr = 0; ++cb; }
+      // one channel block: this tile's window offsets are dead once its DMA is out, so the NEXT tile's ~400 instructions
+      // of raster decoding run here, underneath the MFMAs -- behind the post-loop barrier they sat in front of the DMA issue
+      // with every wave of the workgroup idle (per-tile probe: ~2.5 K of 25 K cycles)
+      if (kc == 3 && more && p.ncb == 1) decode_window(G0 + (int)gridDim.x * BM);
       pq_comp += PQ_NOW() - pq2;
     }
     const unsigned long long pq3 = PQ_NOW();
@@ -695,12 +699,13 @@ __global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParam
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (more) {
-      decode_window(G0 + (int)gridDim.x * BM);
+      if (p.ncb != 1) decode_window(G0 + (int)gridDim.x * BM);
       issue_window(0);
     }
     // ---- epilogue, wave-private: 32 rows x 64 channels at a time through this wave's 4 KB of LDS
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const unsigned long long pe0 = PQ_NOW();
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -711,6 +716,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParam
           win_lds_write_b64(stage_lds + frow * 128 + (((4 * j + g) ^ (frow & 7)) << 4) + fh * 8, v);
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private: no barrier
+      const unsigned long long pe1 = PQ_NOW();
       u32x4_t pkv[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -718,6 +724,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParam
         pkv[it] = win_lds_read_b128(stage_lds + r * 128 + ((ech ^ (r & 7)) << 4));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pkv[0]), "+v"(pkv[1]), "+v"(pkv[2]), "+v"(pkv[3])::"memory");
+      const unsigned long long pe2 = PQ_NOW();
       uint4 pk[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) pk[it] = make_uint4(pkv[it].x, pkv[it].y, pkv[it].z, pkv[it].w);
@@ -740,6 +747,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParam
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the slice is rewritten
+      pq_e1 += pe1 - pe0; pq_e2 += pe2 - pe1; pq_e3 += PQ_NOW() - pe2;
     }
     pq_epi += PQ_NOW() - pq3;
     ++pq_tiles;
@@ -747,6 +755,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParam
   if (p.probe && tid == 0) {
     unsigned long long* o = p.probe + (size_t)blockIdx.x * 16;
     o[0] = PQ_NOW() - pq_t0; o[1] = pq_wait; o[2] = pq_bar; o[3] = pq_comp; o[4] = pq_epi; o[5] = pq_tiles;
+    o[6] = pq_e1; o[7] = pq_e2; o[8] = pq_e3;
   }
 #undef PQ_NOW
   if (p.stats) {

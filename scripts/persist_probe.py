@@ -17,4 +17,4 @@ t = buf.view(-1, 16).cpu().double()
 t = t[t[:, 5] > 0]
 n = t[:, 5].mean().item()
 tot, wait, bar, comp, epi = [t[:, i].mean().item() for i in range(5)]
-print(f'{len(t)} WGs x {n:.1f} tiles | per tile: total {tot/n:7.0f} cyc = dma-wait {wait/n:6.0f} + barrier {bar/n:6.0f} + MFMA steps {comp/n:6.0f} + epilogue {epi/n:6.0f} + rest {(tot-wait-bar-comp-epi)/n:6.0f}')
+print(f'{len(t)} WGs x {n:.1f} tiles | per tile: total {tot/n:7.0f} cyc = dma-wait {wait/n:6.0f} + barrier {bar/n:6.0f} + MFMA steps {comp/n:6.0f} + epilogue {epi/n:6.0f} + rest {(tot-wait-bar-comp-epi)/n:6.0f} | epilogue: stage {t[:,6].mean()/n:6.0f}  read {t[:,7].mean()/n:6.0f}  decode+store+stats {t[:,8].mean()/n:6.0f}')
