@@ -63,7 +63,10 @@ int mpr_conv_set_wgrad_target_wgs(int n);
 int mpr_conv_set_wgrad_tile(int v);
 
 /* weight gradients of 3x3 / stride 1 / pad 1 convolutions (C, K multiples of 64) run on the sliding-window kernel
- * (conv_wgrad_win.hip); 0 switches it off (tests / comparisons); returns the previous setting */
+ * (conv_wgrad_win.hip).  Low byte: 0 = off (tests / comparisons), 1 = on (default), 2 = on with the round-1 wave layouts
+ * (six waves at K = 64), 3 = on with two pixel blocks per chunk at K % 128 == 0 (experiment).  Bits 8.. are timing-
+ * experiment flags: bit 8 = skip the epilogue (results wrong by design), bit 9 = per-wave instead of per-workgroup probe
+ * records (mpr_conv_debug_wgrad_probe).  Returns the previous low byte */
 int mpr_conv_set_wgrad_window(int on);
 
 #ifdef __cplusplus
