@@ -169,15 +169,20 @@ class HipClipMath:
         return out
 
 
-def _mse_term(a32, p32, beta, n, comm, math):
+def _mse_term(a32, p32, beta, n, math):
     """beta * MSELoss(image_emb, profile_emb) over the GLOBAL batch (src/coordination.py:60-64,108-112):
-    -> (loss share summed over ranks, coefficient of (x - other) in the local embedding gradients)."""
+    -> (this rank's share of the loss value, coefficient of (x - other) in the local embedding gradients)."""
     if not beta:
         return None, 0.0
     D = a32.shape[1]
-    local = math.sqdiff_sum(a32, p32)
-    total = comm.all_reduce_sum(local.reshape(1).clone()).reshape(())
-    return total * (float(beta) / (n * D)), 2.0 * float(beta) / (n * D)
+    return math.sqdiff_sum(a32, p32) * (float(beta) / (n * D)), 2.0 * float(beta) / (n * D)
+
+
+def _global_loss(comm, share, mse_share):
+    """The loss VALUE (logging only -- no gradient depends on it): one scalar all-reduce of the ranks' shares, enqueued
+    AFTER the gradient kernels so that its latency is not between the forward and backward halves of the loss stage."""
+    local = share if mse_share is None else share + mse_share
+    return comm.all_reduce_sum(local.reshape(1).clone()).reshape(())
 
 
 def dp_siglip(image_emb, profile_emb, logit_scale, bias, comm, math, beta=0.0):
@@ -193,13 +198,10 @@ def dp_siglip(image_emb, profile_emb, logit_scale, bias, comm, math, beta=0.0):
     uv, inv = math.normalize(a32, p32)
     gathered = comm.all_gather(uv)                                   # [world, 2, b, D]
     share = math.siglip_fwd(gathered, logit_scale, bias, comm.rank, 1.0 / n)
-    loss = comm.all_reduce_sum(share.reshape(1).clone()).reshape(())
-    mse, mse_coef = _mse_term(a32, p32, beta, n, comm, math)
-    if mse is not None:
-        loss = loss + mse
+    mse, mse_coef = _mse_term(a32, p32, beta, n, math)
     d_img, d_prof, dls, db = math.siglip_bwd(gathered, logit_scale, bias, comm.rank, 1.0 / n, uv, inv,
                                              a32 if beta else None, p32 if beta else None, mse_coef)
-    return loss, d_img, d_prof, dls, db
+    return _global_loss(comm, share, mse), d_img, d_prof, dls, db
 
 
 def dp_clip(image_emb, profile_emb, logit_scale, comm, math, beta=0.0):
@@ -216,13 +218,10 @@ def dp_clip(image_emb, profile_emb, logit_scale, comm, math, beta=0.0):
     # row block needs every rank's vector of the other role
     lse, share = math.clip_fwd(gathered, logit_scale, comm.rank, 1.0 / (2.0 * n))
     lse_all = comm.all_gather(lse)                                   # [world, 2, b]
-    loss = comm.all_reduce_sum(share.reshape(1).clone()).reshape(())
-    mse, mse_coef = _mse_term(a32, p32, beta, n, comm, math)
-    if mse is not None:
-        loss = loss + mse
+    mse, mse_coef = _mse_term(a32, p32, beta, n, math)
     d_img, d_prof, dls = math.clip_bwd(gathered, logit_scale, lse, lse_all, comm.rank, 1.0 / (2.0 * n), uv, inv,
                                        a32 if beta else None, p32 if beta else None, mse_coef)
-    return loss, d_img, d_prof, dls
+    return _global_loss(comm, share, mse), d_img, d_prof, dls
 
 
 # ------------------------------------------------------------------------------------------------ gradient buckets
