@@ -528,91 +528,87 @@ __global__ __launch_bounds__(64 * NB) void attn_fwd_kernel(const AttnParams p) {
   bf16x8 qf[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) qf[c] = as_frag(add_bias8(qraw[c], p.bias ? p.bias + h * HD + 16 * c + 8 * hh : nullptr));
-  f32x16 acc[NB];
+  // The scores of one 32-key block are 16 accumulator registers; keeping all of them (8-9 blocks: 128-144 VGPRs) through
+  // the softmax put the kernel at 203 VGPRs -- one 8-wave workgroup per CU, nothing running beside its staging and softmax
+  // phases.  They are formed TWICE instead (28 more MFMAs per wave, identical values): once for the row maximum, once for
+  // exp / sum / P V, one block at a time.
+  auto scores = [&](int j) -> f32x16 {
+    f32x16 sj;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
+    for (int e = 0; e < 16; ++e) sj[e] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    if (j < nblk) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const bf16x8 kf = as_frag(*reinterpret_cast<const uint4*>(Ks + (32 * j + r) * RS + (16 * c + 8 * hh) * 2));
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], acc[j], 0, 0, 0);
-      }
+    for (int c = 0; c < NC; ++c) {
+      const bf16x8 kf = as_frag(*reinterpret_cast<const uint4*>(Ks + (32 * j + r) * RS + (16 * c + 8 * hh) * 2));
+      sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], sj, 0, 0, 0);
     }
-  }
-  // softmax over the keys of this lane's query, in as few VALU instructions per score as possible (they, not the 56
-  // MFMAs, are this kernel's arithmetic): invalid keys (tail of the last block / padding mask) are set to -inf in a
-  // pass that only runs where it can matter; max over the RAW scores (scale > 0), p = exp2(s * c - m * c) with
-  // c = scale * log2(e) as one FMA + v_exp_f32; the 1 / sum normalisation moves behind the P V product.
+    return sj;
+  };
+  // softmax over the keys of this lane's query, in as few VALU instructions per score as possible (they, not the
+  // MFMAs, are this kernel's arithmetic): invalid keys (tail of the last block / padding mask) are excluded through a
+  // per-block bit mask that is only built where it can matter; max over the RAW scores (scale > 0), p = exp2(s * c - m * c)
+  // with c = scale * log2(e) as one FMA + v_exp_f32; the 1 / sum normalisation moves behind the P V product.
   const unsigned char* const mrow = p.mask ? p.mask + (size_t)b * p.T : nullptr;
-  // per key block, bit e of bad[j] = accumulator register e holds an invalid key (tail of the last block / padding mask)
-  uint32_t bad[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    bad[j] = 0;
-    if (j < nblk && (mrow || j == nblk - 1)) {
+  auto bad_bits = [&](int j) -> uint32_t {      // bit e = accumulator register e of block j holds an invalid key
+    uint32_t bad = 0;
+    if (mrow || j == nblk - 1) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int key = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (!(key < p.T && !(mrow && mrow[key]))) bad[j] |= 1u << e;
+        if (!(key < p.T && !(mrow && mrow[key]))) bad |= 1u << e;
       }
     }
-  }
+    return bad;
+  };
   float m = -INFINITY;
+  for (int j = 0; j < nblk; ++j) {
+    const f32x16 sj = scores(j);
+    const uint32_t bad = bad_bits(j);
 #pragma unroll
-  for (int j = 0; j < NB; ++j)
-    if (j < nblk) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (!((bad[j] >> e) & 1u)) m = fmaxf(m, acc[j][e]);
-    }
+    for (int e = 0; e < 16; ++e)
+      if (!((bad >> e) & 1u)) m = fmaxf(m, sj[e]);
+  }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   if (m == -INFINITY) m = 0.f;
   const float c2 = p.scale * 1.4426950408889634f, mc = -m * c2;
   float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < NB; ++j)
-    if (j < nblk) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float pv = __builtin_amdgcn_exp2f(fmaf(acc[j][e], c2, mc));
-        if ((bad[j] >> e) & 1u) pv = 0.f;
-        acc[j][e] = pv;
-        sum += pv;
-      }
-    }
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.f / sum;
-  const float keep_scale = p.p_drop > 0.f ? inv / (1.f - p.p_drop) : inv;
   const unsigned long long rowi = ((unsigned long long)blockIdx.x * p.T + q) * p.T;
   f32x16 o[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  for (int j = 0; j < nblk; ++j) {
+    f32x16 sj = scores(j);
+    const uint32_t bad = bad_bits(j);
 #pragma unroll
-  for (int j = 0; j < NB; ++j)
-    if (j < nblk) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (p.p_drop > 0.f) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int e = 8 * s + i;
-            const int key = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            if (!tb_keep(p.seed, rowi + key, p.p_drop)) acc[j][e] = 0.f;
-          }
-        }
-        float pv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pv[i] = acc[j][8 * s + i];
-        const bf16x8 pf = acc_frag(pv);
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(Vt, TS, 32 * d + r, j, s, hh), pf, o[d], 0, 0, 0);
-      }
+    for (int e = 0; e < 16; ++e) {
+      float pv = __builtin_amdgcn_exp2f(fmaf(sj[e], c2, mc));
+      if ((bad >> e) & 1u) pv = 0.f;
+      sj[e] = pv;
+      sum += pv;
     }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      if (p.p_drop > 0.f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int e = 8 * s2 + i;
+          const int key = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (!tb_keep(p.seed, rowi + key, p.p_drop)) sj[e] = 0.f;
+        }
+      }
+      float pv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pv[i] = sj[8 * s2 + i];
+      const bf16x8 pf = acc_frag(pv);
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(Vt, TS, 32 * d + r, j, s2, hh), pf, o[d], 0, 0, 0);
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  const float keep_scale = p.p_drop > 0.f ? inv / (1.f - p.p_drop) : inv;
 #pragma unroll
   for (int d = 0; d < ND; ++d)
 #pragma unroll
