@@ -497,6 +497,23 @@ __device__ __forceinline__ bf16x8 trans_frag(const unsigned char* img, int TS, i
   return as_frag(make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
 
+// The same operand read from the ROW image ([Tp][HD], row stride RS bytes) with the transposing LDS read: a 16-lane group
+// reads a 4 (rows) x 16 (columns) block -- lane (lq = (lane & 15) >> 2, lp = lane & 3) supplies the address of 4 columns
+// of row lq, lane l16 of the group receives rows 0..3 of column l16 -- so two reads (rows + 0 and + 8) deliver the two
+// groups of four consecutive keys / queries a lane needs at its own column 32 d + (lane & 31).  No transposed copy in LDS
+// (29 KB per operand at 224 tokens, and its staging: eight 2-byte LDS writes per 16 bytes).
+typedef __attribute__((ext_vector_type(4))) short tf_s16x4;
+typedef __attribute__((ext_vector_type(8))) short tf_s16x8;
+__device__ __forceinline__ bf16x8 trans_frag_rows(uint32_t img_lds, int RS, int d, int j, int s, int lane) {
+  const int g16 = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3, hh = lane >> 5;
+  const uint32_t a = img_lds + (uint32_t)((32 * j + 16 * s + 4 * hh + lq) * RS + (32 * d + 16 * (g16 & 1) + 4 * lp) * 2);
+  tf_s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a + (uint32_t)(8 * RS)) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
+  return __builtin_bit_cast(bf16x8, (tf_s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 __device__ __forceinline__ bf16x8 acc_frag(const float* v) {   // 8 accumulator registers -> bf16 operand
   return as_frag(pack8(v));
 }
@@ -508,7 +525,8 @@ __global__ __launch_bounds__(64 * NB) void attn_fwd_kernel(const AttnParams p) {
   constexpr int RS = HD * 2 + 16, NC = HD / 16, ND = HD / 32;
   const int nblk = (p.T + 31) >> 5, Tp = nblk * 32, TS = Tp * 2 + 8;
   unsigned char* const Ks = smem;
-  unsigned char* const Vt = smem + Tp * RS;
+  unsigned char* const Vs = smem + Tp * RS;
+  const uint32_t vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)Vs;
   const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
   const int dm = p.heads * HD;
   const size_t d3 = 3 * (size_t)dm;
@@ -522,7 +540,7 @@ __global__ __launch_bounds__(64 * NB) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) qraw[c] = *reinterpret_cast<const uint4*>(base + (size_t)qc * d3 + 16 * c + 8 * hh);
   stage_store<HD, 64 * NB>(rk, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, nullptr, 0);
-  stage_store<HD, 64 * NB>(rv, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, nullptr, 0, Vt, TS);
+  stage_store<HD, 64 * NB>(rv, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, Vs, RS, nullptr, 0);
   __syncthreads();
   if (w >= nblk) return;
   bf16x8 qf[NC];
@@ -603,7 +621,7 @@ __global__ __launch_bounds__(64 * NB) void attn_fwd_kernel(const AttnParams p) {
       const bf16x8 pf = acc_frag(pv);
 #pragma unroll
       for (int d = 0; d < ND; ++d)
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(Vt, TS, 32 * d + r, j, s2, hh), pf, o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag_rows(vs_lds, RS, d, j, s2, lane), pf, o[d], 0, 0, 0);
     }
   }
   sum += __shfl_xor(sum, 32, 64);
@@ -636,7 +654,7 @@ __global__ __launch_bounds__(64 * NB) void attn_bwd_dq_kernel(const AttnParams p
   const int nblk = (p.T + 31) >> 5, Tp = nblk * 32, TS = Tp * 2 + 8;
   unsigned char* const Ks = smem;
   unsigned char* const Vs = smem + Tp * RS;
-  unsigned char* const Kt = smem + 2 * Tp * RS;
+  const uint32_t ks_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)Ks;
   const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
   const int dm = p.heads * HD;
   const size_t d3 = 3 * (size_t)dm;
@@ -656,7 +674,7 @@ __global__ __launch_bounds__(64 * NB) void attn_bwd_dq_kernel(const AttnParams p
     ovraw[c] = *reinterpret_cast<const uint4*>(orow + 16 * c + 8 * hh);
   }
   const float lse = p.lse[(size_t)blockIdx.x * p.T + qc];
-  stage_store<HD, 64 * NB>(rk, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, Kt, TS);
+  stage_store<HD, 64 * NB>(rk, p.bias ? p.bias + dm + h * HD : nullptr, p.T, Tp, Ks, RS, nullptr, 0);
   stage_store<HD, 64 * NB>(rv, p.bias ? p.bias + 2 * dm + h * HD : nullptr, p.T, Tp, Vs, RS, nullptr, 0);
   __syncthreads();
   if (w >= nblk) return;
@@ -712,7 +730,7 @@ __global__ __launch_bounds__(64 * NB) void attn_bwd_dq_kernel(const AttnParams p
       const bf16x8 dsf = acc_frag(ds + 8 * s2);
 #pragma unroll
       for (int d = 0; d < ND; ++d)
-        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(Kt, TS, 32 * d + r, j, s2, hh), dsf, dq[d], 0, 0, 0);
+        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag_rows(ks_lds, RS, d, j, s2, lane), dsf, dq[d], 0, 0, 0);
     }
   }
   if (q < p.T) {
@@ -730,16 +748,16 @@ __global__ __launch_bounds__(64 * NB) void attn_bwd_dq_kernel(const AttnParams p
 
 // backward, part 2 (key on the lane): dV^T = dO^T P, dK^T = Q^T dS
 template <int HD, int NB>
-__global__ __launch_bounds__(64 * NB) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(64 * NB) void attn_bwd_dkv_kernel(const AttnParams p) {      // (176 VGPRs: one 8-wave workgroup per CU; a 128-VGPR cap spills 82)
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int RS = HD * 2 + 16, NC = HD / 16, ND = HD / 32;
   const int nblk = (p.T + 31) >> 5, Tp = nblk * 32, TS = Tp * 2 + 8;
   unsigned char* const Qs = smem;
   unsigned char* const Os = smem + Tp * RS;
-  unsigned char* const Qt = smem + 2 * Tp * RS;
-  unsigned char* const Ot = Qt + HD * TS;
-  float* const lse_s = reinterpret_cast<float*>(Ot + HD * TS);
+  float* const lse_s = reinterpret_cast<float*>(smem + 2 * Tp * RS);
+  const uint32_t qs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)Qs;
+  const uint32_t os_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)Os;
   float* const del_s = lse_s + Tp;
   const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
   const int dm = p.heads * HD;
@@ -760,8 +778,8 @@ __global__ __launch_bounds__(64 * NB) void attn_bwd_dkv_kernel(const AttnParams 
     lse_s[t] = t < p.T ? -1.4426950408889634f * p.lse[(size_t)blockIdx.x * p.T + t] : 0.f;     // (-lse * log2 e)
     del_s[t] = t < p.T ? p.delta[(size_t)blockIdx.x * p.T + t] : 0.f;
   }
-  stage_store<HD, 64 * NB>(rq, p.bias ? p.bias + h * HD : nullptr, p.T, Tp, Qs, RS, Qt, TS);
-  stage_store<HD, 64 * NB>(ro, nullptr, p.T, Tp, Os, RS, Ot, TS);
+  stage_store<HD, 64 * NB>(rq, p.bias ? p.bias + h * HD : nullptr, p.T, Tp, Qs, RS, nullptr, 0);
+  stage_store<HD, 64 * NB>(ro, nullptr, p.T, Tp, Os, RS, nullptr, 0);
   __syncthreads();
   if (w >= nblk) return;
   const bool key_valid = key < p.T && !(p.mask && p.mask[(size_t)b * p.T + kc]);
@@ -806,8 +824,8 @@ __global__ __launch_bounds__(64 * NB) void attn_bwd_dkv_kernel(const AttnParams 
       const bf16x8 dsf = acc_frag(ds + 8 * s2);
 #pragma unroll
       for (int d = 0; d < ND; ++d) {
-        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(Ot, TS, 32 * d + r, i, s2, hh), pf, dv[d], 0, 0, 0);
-        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag(Qt, TS, 32 * d + r, i, s2, hh), dsf, dk[d], 0, 0, 0);
+        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag_rows(os_lds, RS, d, i, s2, lane), pf, dv[d], 0, 0, 0);
+        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trans_frag_rows(qs_lds, RS, d, i, s2, lane), dsf, dk[d], 0, 0, 0);
       }
     }
   }
@@ -974,7 +992,7 @@ int mpr_attn_fwd(const void* qkv, const float* bias, const void* key_padding_mas
   AttnParams p = {(const uint16_t*)qkv, bias, (const unsigned char*)key_padding_mask, (uint16_t*)out, lse, nullptr, nullptr,
                   nullptr, B, T, heads, scale, p_drop, seed};
   const int Tp = (T + 31) / 32 * 32;
-  const size_t lds = (size_t)Tp * (head_dim * 2 + 16) + (size_t)head_dim * (Tp * 2 + 8);
+  const size_t lds = 2 * (size_t)Tp * (head_dim * 2 + 16);      // K and V row images
   hipStream_t st = (hipStream_t)stream;
   if (head_dim == 64) {
     if (int rc = set_lds(attn_fwd_kernel<64, 8>, lds)) return rc;
@@ -999,8 +1017,8 @@ int mpr_attn_bwd(const void* qkv, const float* bias, const void* key_padding_mas
                   (const uint16_t*)dout, delta, (uint16_t*)dqkv, B, T, heads, scale, p_drop, seed};
   const int Tp = (T + 31) / 32 * 32;
   const size_t rs = head_dim * 2 + 16, ts = Tp * 2 + 8;
-  const size_t lds_q = 2 * Tp * rs + head_dim * ts;
-  const size_t lds_kv = 2 * Tp * rs + 2 * head_dim * ts + 2 * Tp * sizeof(float);
+  const size_t lds_q = 2 * Tp * rs;                              // K and V row images
+  const size_t lds_kv = 2 * Tp * rs + 2 * Tp * sizeof(float);   // Q and dO row images + lse, delta
   hipStream_t st = (hipStream_t)stream;
   if (head_dim == 64) {
     if (int rc = set_lds(attn_bwd_dq_kernel<64, 8>, lds_q)) return rc;

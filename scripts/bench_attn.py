@@ -3,6 +3,7 @@ transformer's (225 tokens): forward, and backward (dQ kernel + dK/dV kernel)."""
 import sys, torch
 sys.path.insert(0, '.')
 from multimodal_plankton_recognition_amd import transformer_mixed as TM
+torch.manual_seed(0)
 def timeit(fn, n=20):
     for _ in range(5): fn()
     torch.cuda.synchronize()
@@ -19,4 +20,4 @@ for B, T, heads, hd in [(128, 197, 12, 64), (128, 225, 12, 64), (64, 257, 2, 32)
     dout = torch.randn_like(out)
     tf = timeit(lambda: TM.attn_fwd(qkv, bias, None, B, T, heads, 0.0, 0))
     tb = timeit(lambda: TM.attn_bwd(qkv, bias, None, out, dout, lse, B, T, heads, 0.0, 0))
-    print(f'B={B} T={T} heads={heads} hd={hd}: forward {tf:6.1f} us   backward (dQ + dK/dV) {tb:6.1f} us   checksum {out.float().abs().sum().item():.6e}', flush=True)
+    print(f'B={B} T={T} heads={heads} hd={hd}: forward {tf:6.1f} us   backward (dQ + dK/dV) {tb:6.1f} us   checksums {out.float().abs().sum().item():.8e} {TM.attn_bwd(qkv, bias, None, out, dout, lse, B, T, heads, 0.0, 0).float().abs().sum().item():.8e}', flush=True)
