@@ -59,7 +59,7 @@ int mpr_conv_set_wgrad_dma_min_pixels(int pixels);
 int mpr_conv_set_wgrad_target_wgs(int n);
 
 /* output tile of the LDS-DMA weight-gradient kernel on big one-tap GEMMs (transformer linears): 0 = 128 x 128 (4 waves),
- * 1 = 256 x 256 (16 waves), 2 = 256 x 128, 3 = 128 x 256 (8 waves); returns the previous value */
+ * 1 = 256 x 256 (16 waves; default), 2 = 256 x 128, 3 = 128 x 256 (8 waves); returns the previous value */
 int mpr_conv_set_wgrad_tile(int v);
 
 /* weight gradients of 3x3 / stride 1 / pad 1 convolutions (C, K multiples of 64) run on the sliding-window kernel

@@ -420,7 +420,10 @@ extern "C" int mpr_conv_set_wgrad_target_wgs(int n) {   // tuning knob; returns 
   g_wgrad_target_wgs = n;
   return old;
 }
-static int g_wgrad_tile = 0;
+// (default 1 since round 2: alone the 256 x 256 tile is slower on three of four transformer shapes, but INSIDE the step --
+//  beside the data-gradient chain, where fewer and fatter workgroups cost less CU-time -- ViT-B/16 + ProfileTransformer at
+//  batch 128 runs 58.5 ms per step with it against 61.2 (tile 2 / 3: 60.0))
+static int g_wgrad_tile = 1;
 extern "C" int mpr_conv_set_wgrad_tile(int v) {   // tuning knob (see mpr_conv_wgrad); returns the previous value
   const int old = g_wgrad_tile;
   g_wgrad_tile = v;
@@ -512,8 +515,8 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
     // LDS-DMA ring kernel: 64-pixel chunks, 2 workgroups per CU
     int WM = K <= 64 ? 1 : 2;
     int WN = p.Ng <= 64 ? 1 : ((C == 64 && p.Ng % 192 == 0) ? 3 : 2);
-    // big one-tap GEMMs (transformer linears): larger output tiles = more FLOP per LDS-DMA byte (g_wgrad_tile: 0 off,
-    // 1 = 256 x 256 on 16 waves, 2 = 256 x 128, 3 = 128 x 256 on 8 waves)
+    // big one-tap GEMMs (transformer linears): larger output tiles = more FLOP per LDS-DMA byte (g_wgrad_tile: 0 = 128 x 128,
+    // 1 = 256 x 256 on 16 waves (default), 2 = 256 x 128, 3 = 128 x 256 on 8 waves)
     if (g_wgrad_tile && R * S == 1 && K >= 512 && p.Ng >= 512 && p.Mpix >= 8192) {
       WM = g_wgrad_tile == 3 ? 2 : 4;
       WN = g_wgrad_tile == 2 ? 2 : 4;
