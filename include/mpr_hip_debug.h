@@ -25,7 +25,7 @@ int mpr_conv_set_window_variant(int v);
  * returns the previous threshold */
 int mpr_conv_set_dma_min_rows(int rows);
 
-/* tile / ring-depth variant of the LDS-DMA kernel (tuning knob, see conv_igemm.hip; default 0, 0) */
+/* tile / ring-depth variant of the LDS-DMA kernel (tuning knob, see conv_igemm.hip; default 0, 7) */
 int mpr_conv_set_variant(int narrow, int wide);
 
 /* stride-2 data gradient: regroup rows into the 4 (h mod 2, w mod 2) classes so a tile walks only the taps that

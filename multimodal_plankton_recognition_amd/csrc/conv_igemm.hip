@@ -815,7 +815,9 @@ extern "C" int mpr_conv_set_dma_min_rows(int rows) {   // tuning / test knob; re
 //   wide   (N > 64) : 0 = 256x128, 3 stages, 8 waves    1 = 128x128, 2 stages (2 WG/CU)   2 = 128x128, 3 stages
 //                     3 = 128x128, BK 32, 3 stages (3 WG/CU)   4 = 128x128, BK 32, 4 stages (2 WG/CU)
 //                     5 = 256x128, BK 32, 3 stages (2 WG/CU)   6 = 256x128, BK 32, 4 stages (1 WG/CU)
-static int g_variant_narrow = 0, g_variant_wide = 1;
+// (wide 7 since round 2: 256 x 256 tiles on 16 waves for every output width >= 256 -- inside the step, beside the weight-
+//  gradient stream, fewer and fatter workgroups win: C5 share 59.0 -> 57.1 ms, C3 10.21 -> 10.10 ms in the in-process A/B)
+static int g_variant_narrow = 0, g_variant_wide = 7;
 extern "C" int mpr_conv_set_variant(int narrow, int wide) {
   g_variant_narrow = narrow;
   g_variant_wide = wide;
@@ -861,6 +863,8 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   for (int r = 0; r < p.R && r * p.S < 32; ++r) p.rowpat |= 1u << (r * p.S);
   int mode, BM, BN;
   igemm_config(p.M, p.Nout, p.sC, p.R * p.S, &mode, &BM, &BN);
+  const bool bnb = dgrad && p.bnb_x != nullptr;       // (its slice rows and their zeroing: the caller's, see conv_dgrad_impl)
+  if (bnb && BN != 64) { BM = 128; BN = 128; }        // the fused BatchNorm-backward epilogue exists on the default tiles only
   const bool narrow = BN == 64;
   // algorithmic flops: a strided data gradient touches each (pixel, tap) pair of the forward conv once
   const double flops = 2.0 * (double)p.M * (double)p.Nout * (double)p.Kg / (dgrad ? p.sh * p.sw : 1);
@@ -881,11 +885,10 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   }
   // other strided data gradients (3/4 of the taps are holes) run better on the deep 256x128 ring
   const bool s2dgrad = dgrad && mode == 1 && !narrow && (p.sh == 2 || p.sw == 2) && p.par_rows == 0;
-  if (s2dgrad) BM = 256;
+  if (s2dgrad) { BM = 256; BN = 128; }
   p.ntn = ceil_div(p.Nout, BN);
   const int gm = ceil_div(p.M, BM);
   dim3 grid(gm * p.ntn);
-  const bool bnb = dgrad && p.bnb_x != nullptr;       // (its slice rows and their zeroing: the caller's, see conv_dgrad_impl)
   if (!bnb) {
     p.stat_slices = (p.stats && !dgrad) ? g_stat_slices : 0;
     const bool prezeroed = mpr_conv_take_prezeroed();

@@ -30,7 +30,7 @@ for name, Bt, T, C, K in [('vit qkv', 128, 197, 768, 2304), ('vit proj', 128, 19
         td = timeit(lambda: ops.conv_dgrad(dy, wd, g, x.shape))
         row.append(f'v{v} fwd {tf:6.1f}us {flop/tf/1e6:4.0f}TF dgrad {td:6.1f}us {flop/td/1e6:4.0f}TF{"" if ok else " MISMATCH"}')
     print(' | '.join(row), flush=True)
-N.query('mpr_conv_set_variant', 0, 1)
+N.query('mpr_conv_set_variant', 0, 7)
 
 print('weight gradient, tile knob 0..3 (us):')
 for name, Bt, T, C, K in [('vit qkv', 128, 197, 768, 2304), ('vit proj', 128, 197, 768, 768), ('vit fc1', 128, 197, 768, 3072),

@@ -26,4 +26,4 @@ for name, H, C in [('l2.0 64->128 @56', 56, 64), ('l3.0 128->256 @28', 28, 128),
         r = ops.conv_dgrad(dy, wd3, g3, x.shape)
         ref = r if ref is None else ref
         print(f'{name} narrow {nv} wide {wv}: fwd {f3:6.1f}  dgrad {d3:6.1f}  {"same" if torch.equal(r, ref) else "DIFF"}', flush=True)
-N.query('mpr_conv_set_variant', 0, 1)
+N.query('mpr_conv_set_variant', 0, 7)
