@@ -897,6 +897,10 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, alpha=1.0, bet
     M, K = (a2[1], a2[0]) if trans_a else (a2[0], a2[1])
     Kb, Nn = (b2[1], b2[0]) if trans_b else (b2[0], b2[1])
     assert K == Kb, f'gemm: inner dimensions differ ({K} vs {Kb})'
+    if not (a.is_contiguous() and b.is_contiguous() and (out is None or out.is_contiguous())):
+        # (N.ptr accepts any dense permutation -- conv filters are addressed through strides -- but the leading
+        # dimensions passed below are those of row-major operands)
+        raise N.NativeLibraryError('gemm: operands must be row-major contiguous (use trans_a / trans_b for transposes)')
     if out is None:
         out = torch.empty((nb, M, Nn) if batched else (M, Nn), dtype=F32, device=a.device)
     N.call('mpr_gemm_f32', a, b, out, bias, M, Nn, K, a2[1], b2[1], Nn, int(trans_a), int(trans_b), float(alpha),
