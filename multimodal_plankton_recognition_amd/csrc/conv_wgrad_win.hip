@@ -77,10 +77,12 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid % 3, wh = (wid / 3) & 1;                      // filter row, channel half
   const int wk = PS == 1 ? wid / 6 : 0, wp = PS == 1 ? 0 : wid / 6;   // output-channel slab | pixel half of the chunk
-  // consecutive blocks share the pixel range (their dy / x rows come from the same L2 lines)
-  const int cb = blockIdx.x % p.ncb;
-  const int kt = (blockIdx.x / p.ncb) % p.nkt;
-  const int split = blockIdx.x / (p.ncb * p.nkt);
+  // consecutive work items share the pixel range; the hardware deals consecutive blocks to DIFFERENT XCDs, so the items are
+  // renumbered to give every XCD one contiguous run (their dy / x rows then come from the same L2 lines)
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int cb = bid % p.ncb;
+  const int kt = (bid / p.ncb) % p.nkt;
+  const int split = bid / (p.ncb * p.nkt);
   const int c0 = split * p.cps;
   int c1 = c0 + p.cps;
   if (c1 > p.total_chunks) c1 = p.total_chunks;

@@ -619,7 +619,9 @@ __global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParam
   unsigned long long pq_wait = 0, pq_bar = 0, pq_comp = 0, pq_epi = 0, pq_tiles = 0, pq_e1 = 0, pq_e2 = 0, pq_e3 = 0;
 #define PQ_NOW() (p.probe ? __builtin_readcyclecounter() : 0ull)
   const unsigned long long pq_t0 = PQ_NOW();
-  int tile = blockIdx.x;
+  // tiles of one round go to the XCDs in contiguous runs (as in the plain kernel): neighbouring tiles' windows overlap by
+  // the halo (45 % of a window at W = 56), which then comes from that XCD's L2 instead of HBM a second time
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
   if (tile < ntiles) {
     decode_window(tile * BM);
     issue_window(0);
