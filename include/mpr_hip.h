@@ -190,6 +190,17 @@ int mpr_bn_apply_fin(const void* x, const float* slices, int nsl, long long coun
                      float* running_mean /* may be NULL */, float* running_var, float momentum, float eps, float* scale,
                      float* shift, float* mean, float* invstd, const void* residual /* may be NULL */, int relu, void* y,
                      long long rows, int C, void* stream);
+/* the output of a residual block with a projection shortcut in ONE pass: y = act(BN(x) + bf16(BN_r(xr))), x and xr the raw
+ * outputs of conv2 and of the 1x1 shortcut conv (timm BasicBlock.forward: `shortcut = self.downsample(shortcut); x +=
+ * shortcut; x = self.act2(x)`; src/profile_encoder.py:139-147) -- the normalised shortcut map is never stored; bit-identical
+ * to mpr_bn_apply_fin(xr) followed by mpr_bn_apply_fin(x, residual).  Either BatchNorm may be finalized already
+ * (slices == NULL: scale / shift are inputs) or pending (slices [nsl][2][C], as in mpr_bn_apply_fin).  C <= 512. */
+int mpr_bn_apply_dual(const void* x, const float* slices, int nsl, long long count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                      float* mean, float* invstd, const void* xr, const float* slices_r, int nsl_r, long long count_r,
+                      const float* gamma_r, const float* beta_r, float* running_mean_r, float* running_var_r,
+                      float momentum_r, float eps_r, float* scale_r, float* shift_r, float* mean_r, float* invstd_r,
+                      int relu, void* y, long long rows, int C, void* stream);
 int mpr_bn_bwd_apply_fin(const void* dy, const void* y, const void* x, const float* slices, int nsl, long long count,
                          const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                          int accumulate, const float* scale, const float* shift, int mask_mode, void* dx,

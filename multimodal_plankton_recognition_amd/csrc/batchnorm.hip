@@ -291,6 +291,52 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
   }
 }
 
+// A downsampling block's output in ONE pass: y = act(BN(x) + bf16(BN_r(xr))), both BatchNorms on raw conv outputs.  The
+// shortcut's normalised map ("identity") is never written and read back; it is rounded to bf16 in the register exactly
+// as the stored map was, so the result is bit-identical to bn_apply(xr) followed by bn_apply(x, residual).
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_apply_dual_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ slices, int nsl,
+                                                            const BnFinalizeArgs fin, const bf16_t* __restrict__ xr,
+                                                            const float* __restrict__ scale_r,
+                                                            const float* __restrict__ shift_r,
+                                                            const float* __restrict__ slices_r, int nsl_r,
+                                                            const BnFinalizeArgs fin_r, bf16_t* __restrict__ y,
+                                                            long long nvec, int cg) {
+  const int g = threadIdx.x % cg;
+  float sc[8], sh[8], scr[8], shr[8];
+  __shared__ float fl[2][FIN_MAX_C];
+  auto coefs = [&](const float* slc, int n, const BnFinalizeArgs& a, const float* scp, const float* shp, float* c, float* h) {
+    if (slc) {
+      bn_block_finalize<0>(slc, n, cg * 8, a, fl);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { c[e] = fl[0][g * 8 + e]; h[e] = fl[1][g * 8 + e]; }
+      __syncthreads();          // fl is reused by the second BatchNorm
+    } else {
+      *reinterpret_cast<float4*>(c) = reinterpret_cast<const float4*>(scp)[g * 2];
+      *reinterpret_cast<float4*>(c + 4) = reinterpret_cast<const float4*>(scp)[g * 2 + 1];
+      *reinterpret_cast<float4*>(h) = reinterpret_cast<const float4*>(shp)[g * 2];
+      *reinterpret_cast<float4*>(h + 4) = reinterpret_cast<const float4*>(shp)[g * 2 + 1];
+    }
+  };
+  coefs(slices, nsl, fin, scale, shift, sc, sh);
+  coefs(slices_r, nsl_r, fin_r, scale_r, shift_r, scr, shr);
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+       v += (long long)gridDim.x * blockDim.x) {
+    float f[8], r[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[v], f);
+    unpack8(reinterpret_cast<const uint4*>(xr)[v], r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = fmaf(f[e], sc[e], sh[e]) + round_bf16(fmaf(r[e], scr[e], shr[e]));
+      if (ACT == 1) t = fmaxf(t, 0.f);
+      f[e] = t;
+    }
+    reinterpret_cast<uint4*>(y)[v] = pack8(f);
+  }
+}
+
 // mask modes for the backward passes
 enum { MASK_NONE = 0, MASK_Y = 1, MASK_RECOMPUTE = 2, MASK_SILU = 3 };   // MASK_SILU: dz = dy * silu'(x*scale + shift)
 
@@ -564,6 +610,39 @@ int mpr_bn_apply_fin(const void* x, const float* slices, int nsl, long long coun
   a.scale = scale; a.shift = shift; a.mean_out = mean; a.invstd_out = invstd;
   return launch_bn_apply((const bf16_t*)x, scale, shift, (const bf16_t*)residual, relu, (bf16_t*)y, nvec, C, grid, BLK,
                          slices, nsl, a, (hipStream_t)stream);
+}
+
+// y = act(BN(x) + bf16(BN_r(xr))) in one pass (bn_apply_dual_kernel).  Each BatchNorm is either finalized (slices == NULL:
+// scale / shift are read) or pending as in mpr_bn_apply_fin (slices [nsl][2][C]: every workgroup derives the coefficients,
+// workgroup 0 writes scale, shift, mean, invstd and updates the running statistics).  C <= 512.
+int mpr_bn_apply_dual(const void* x, const float* slices, int nsl, long long count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                      float* mean, float* invstd, const void* xr, const float* slices_r, int nsl_r, long long count_r,
+                      const float* gamma_r, const float* beta_r, float* running_mean_r, float* running_var_r,
+                      float momentum_r, float eps_r, float* scale_r, float* shift_r, float* mean_r, float* invstd_r,
+                      int relu, void* y, long long rows, int C, void* stream) {
+  MPR_REQUIRE(C % 8 == 0 && C <= FIN_MAX_C, "mpr_bn_apply_dual: C must be a multiple of 8, <= 512 (got %d)", C);
+  MPR_REQUIRE(x && xr && y && scale && shift && scale_r && shift_r, "mpr_bn_apply_dual: null pointer");
+  MPR_REQUIRE(!slices || (nsl > 0 && mean && invstd), "mpr_bn_apply_dual: pending statistics need nsl > 0, mean, invstd");
+  MPR_REQUIRE(!slices_r || (nsl_r > 0 && mean_r && invstd_r),
+              "mpr_bn_apply_dual: pending shortcut statistics need nsl > 0, mean, invstd");
+  MPR_REQUIRE(relu == 0 || relu == 1, "mpr_bn_apply_dual: relu must be 0 or 1 (got %d)", relu);
+  const long long nvec = rows * C / 8;
+  const int BLK = cg_block(C / 8), grid = ew_grid(nvec, BLK);
+  BnFinalizeArgs a = {}, b = {};
+  a.count = (float)count; a.momentum = momentum; a.eps = eps;
+  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.scale = scale; a.shift = shift; a.mean_out = mean; a.invstd_out = invstd;
+  b.count = (float)count_r; b.momentum = momentum_r; b.eps = eps_r;
+  b.gamma = gamma_r; b.beta = beta_r; b.running_mean = running_mean_r; b.running_var = running_var_r;
+  b.scale = scale_r; b.shift = shift_r; b.mean_out = mean_r; b.invstd_out = invstd_r;
+  hipStream_t st = (hipStream_t)stream;
+#define ARGS (const bf16_t*)x, scale, shift, slices, nsl, a, (const bf16_t*)xr, scale_r, shift_r, slices_r, nsl_r, b, (bf16_t*)y, nvec, C / 8
+  if (relu) bn_apply_dual_kernel<1><<<grid, BLK, 0, st>>>(ARGS);
+  else bn_apply_dual_kernel<0><<<grid, BLK, 0, st>>>(ARGS);
+#undef ARGS
+  MPR_LAUNCH_CHECK("bn_apply_dual_kernel");
+  return MPR_OK;
 }
 
 // mask_mode: 0 none, 1 relu mask from y (y > 0), 2 recompute relu mask from x*scale+shift, 3 SiLU derivative at x*scale+shift

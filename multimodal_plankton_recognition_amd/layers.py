@@ -145,11 +145,13 @@ class BasicBlockFn(torch.autograd.Function):
             wfd, wdd = ops.packed_weights(wd, cd, need_bwd)
             xd, sd = ops.conv_fwd(x, wfd, cd, train)
             std = _bn_coefs(sd, _rows(xd), mod.downsample[1], train, xd, defer=True, want_bwd=need_bwd)
-            identity = ops.bn_apply(xd, std, None, False)
+            # both BatchNorms, the add and the ReLU in one pass: the normalised shortcut map is never stored
+            out = ops.bn_apply_dual(x2, st2, xd, std, True)
+            if out is None:
+                out = ops.bn_apply(x2, st2, ops.bn_apply(xd, std, None, False), True)
         else:
             xd = std = wdd = None
-            identity = x
-        out = ops.bn_apply(x2, st2, identity, True)
+            out = ops.bn_apply(x2, st2, x, True)
         if need_bwd:
             ctx.save_for_backward(x, x1, a1, x2, out, xd, w1, w2, wd, g1, g2, gd, b1, b2, bd)
             ctx.misc = (st1, st2, std, c1, c2, cd, wd1, wd2, wdd)

@@ -699,6 +699,30 @@ def bn_apply(x, st, residual=None, relu=True):
     return y
 
 
+DUAL_BN_APPLY = os.environ.get('MPR_DUAL_BN_APPLY', '1') != '0'
+
+
+def bn_apply_dual(x, st, xr, st_r, relu=True):
+    """act(BN(x) + bf16(BN_r(xr))) in one pass -- a projection-shortcut block's output without storing the normalised
+    shortcut map (bit-identical to bn_apply(xr, st_r, None, False) followed by bn_apply(x, st, that, relu)); None when the
+    kernel does not cover the case (C > 512)."""
+    C = x.shape[-1]
+    if not DUAL_BN_APPLY or C > 512 or C % 8 or xr.shape != x.shape:
+        return None
+    y = torch.empty_like(x)
+
+    def side(s):
+        if s.pending is None:
+            return [None, 0, 0, None, None, None, None, 0.0, 0.0, s.scale, s.shift, None, None]
+        slices, count, bn = s.pending
+        s.pending = None
+        return [slices, slices.shape[0], count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                float(bn.momentum), float(bn.eps), s.scale, s.shift, s.mean, s.invstd]
+    a, b = side(st), side(st_r)
+    N.call('mpr_bn_apply_dual', x, *a, xr, *b, int(relu), y, x.numel() // C, C)
+    return y
+
+
 MASK_NONE, MASK_Y, MASK_RECOMPUTE = 0, 1, 2
 
 

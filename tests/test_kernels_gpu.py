@@ -228,6 +228,41 @@ def test_batchnorm_train_fwd_bwd(C, rows, res):
     assert_close_bf16(dz, (dy.float() * mask).reshape(1, rows, C), 'bn bwd dz')
 
 
+@pytest.mark.parametrize('C,rows', [(128, 3000), (512, 130), (8, 5000), (24, 301)])
+@pytest.mark.parametrize('mode', ['pending', 'finalized', 'eval'])
+def test_projection_shortcut_output_in_one_pass(C, rows, mode):
+    """act(BN(x) + bf16(BN_r(xr))) (mpr_bn_apply_dual) == the two passes it replaces, bit for bit: output, saved
+    statistics and running statistics -- with the statistics finalized inside the kernel (what a training block does),
+    finalized before it, and in eval mode."""
+    ops = _ops()
+    x = bf(rnd(rows, C, seed=30) * 1.5 + 0.3).to(DEV).reshape(1, rows, C)
+    xr = bf(rnd(rows, C, seed=31) * 0.7 - 0.2).to(DEV).reshape(1, rows, C)
+    train, defer = mode != 'eval', mode == 'pending'
+
+    def run(dual):
+        bn, bnr = _BN(C, 32), _BN(C, 33)
+        st = ops.bn_coefs(None, rows, bn, train, x, defer=defer, want_bwd=True)
+        str_ = ops.bn_coefs(None, rows, bnr, train, xr, defer=defer, want_bwd=True)
+        assert (st.pending is not None) == defer
+        if dual:
+            y = ops.bn_apply_dual(x, st, xr, str_, True)
+            assert y is not None and st.pending is None and str_.pending is None
+        else:
+            y = ops.bn_apply(x, st, ops.bn_apply(xr, str_, None, False), True)
+        return y, [st.scale, st.shift, st.mean, st.invstd, str_.scale, str_.shift, str_.mean, str_.invstd,
+                   bn.running_mean, bn.running_var, bnr.running_mean, bnr.running_var]
+    y1, s1 = run(True)
+    y0, s0 = run(False)
+    assert torch.equal(y1, y0)
+    for a, b in zip(s1, s0):
+        assert torch.equal(a, b)
+    ref = F.relu(F.batch_norm(x.float().cpu()[0], None, None, _BN(C, 32).weight.cpu(), _BN(C, 32).bias.cpu(), True)
+                 + F.batch_norm(xr.float().cpu()[0], None, None, _BN(C, 33).weight.cpu(), _BN(C, 33).bias.cpu(), True)) \
+        if train else None
+    if ref is not None:
+        assert_close_bf16(y1, ref.reshape(1, rows, C), 'dual bn apply', atol=3e-2)
+
+
 def test_bn_relu_maxpool_2d_and_1d():
     ops = _ops()
     for dims in (2, 1):
