@@ -289,7 +289,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = bid / p.ntn, nt = bid - mt * p.ntn;
+  int mt = bid / p.ntn;
+  const int nt = bid - mt * p.ntn;
+  // parity classes: the four classes of one pixel range are NEIGHBOURS in launch order (they read the same dy rows: one
+  // HBM fetch per XCD instead of four) -- which also spreads the heavy class (4 taps of a 3x3 filter) over the whole launch
+  // instead of leaving it for the tail
+  if (DGRAD && p.par_rows > 0) mt = (mt & 3) * (p.par_rows / BM) + (mt >> 2);
   const int m0 = mt * BM, n0 = nt * BN;
 #define MPR_STAMP(k) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
   MPR_STAMP(0);
