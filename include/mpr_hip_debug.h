@@ -18,6 +18,10 @@ extern "C" {
  * taps read it at shifted LDS rows); 0 switches it off (tests / comparisons); returns the previous setting */
 int mpr_conv_set_window(int on);
 
+/* forward convolutions on maps narrower than `w` pixels take the LDS-DMA implicit GEMM although the shifted-window kernel is
+ * eligible (its padded raster costs (W+1)(H+1) / WH of the work: +31 % at 7 x 7); 0 = never, default 8; returns the previous value */
+int mpr_conv_set_window_fwd_min_width(int w);
+
 /* tile / weight-ring variant of the shifted-window kernel (tuning knob, see conv_win.hip; default 5) */
 int mpr_conv_set_window_variant(int v);
 

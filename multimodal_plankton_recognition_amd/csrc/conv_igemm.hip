@@ -988,10 +988,23 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   return MPR_OK;
 }
 
+// Forward convolutions on maps narrower than this take the LDS-DMA implicit GEMM although the shifted-window kernel is
+// eligible: the padded raster of the window kernel computes (W+1)(H+1) positions per image (+31 % at 7 x 7) and the wide
+// 256 x 256 tile of the implicit GEMM holds fewer CUs for the same work
+static int g_win_fwd_min_w = 8;   // layer4's 7 x 7 maps: 9.98 vs 10.02 ms per C3 step (scripts/step_ab_flags.py)
+int mpr_conv_set_window_fwd_min_width(int w) {
+  const int old = g_win_fwd_min_w;
+  g_win_fwd_min_w = w;
+  return old;
+}
+static inline bool win_fwd(long long M, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw) {
+  return W >= g_win_fwd_min_w && mpr_win_eligible(M, H, W, C, K, R, S, sh, sw, ph, pw, g_dma_min_rows);
+}
+
 // Rows of the BatchNorm partial-sum buffer mpr_conv_fwd will write (slice rows, or one per row tile).
 int mpr_conv_fwd_stat_rows(int B, int P, int Q, int K, int C, int R, int S, int sh, int sw, int ph, int pw) {
   if (g_stat_slices > 0) return g_stat_slices;
-  if (mpr_win_eligible((long long)B * P * Q, P, Q, C, K, R, S, sh, sw, ph, pw, g_dma_min_rows))   // (stride 1: H == P)
+  if (win_fwd((long long)B * P * Q, P, Q, C, K, R, S, sh, sw, ph, pw))   // (stride 1: H == P)
     return mpr_win_stat_rows(B, P, Q, K);
   int mode, BM, BN;
   igemm_config((long long)B * P * Q, K, C, R * S, &mode, &BM, &BN);
@@ -1012,7 +1025,7 @@ int mpr_conv_fwd(const void* x, const void* w_fwd, void* y, float* stats, int B,
   MPR_REQUIRE(P > 0 && Q > 0, "mpr_conv_fwd: empty output");
   MPR_REQUIRE((long long)B * H * W * C < (1ll << 31) && (long long)B * P * Q * K < (1ll << 31),
               "mpr_conv_fwd: tensor exceeds 2^31 elements");
-  if (mpr_win_eligible((long long)B * P * Q, H, W, C, K, R, S, sh, sw, ph, pw, g_dma_min_rows)) {
+  if (win_fwd((long long)B * P * Q, H, W, C, K, R, S, sh, sw, ph, pw)) {
     // 3x3 / stride 1 / pad 1: shifted-window kernel (conv_win.hip)
     void* tok = mpr_prof_begin(6, 2.0 * (double)B * P * Q * K * 9.0 * C, (hipStream_t)stream);      // kind 6: window fwd
     mpr_prof_bytes(tok, 2.0 * ((double)B * H * W * C + 9.0 * C * K + (double)B * P * Q * K));

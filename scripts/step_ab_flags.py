@@ -1,10 +1,10 @@
 """In-process A/B of module-level switches of ops.py on the C3 step (same GPU, same clocks, alternating):
-    python scripts/step_ab_flags.py "DUAL_BN_APPLY=False" "DUAL_BN_BWD=False" ...
-Every setting is applied alone (all others at their defaults) and measured `reps` times, interleaved with the default."""
+    python scripts/step_ab_flags.py "DUAL_BN_APPLY=False" "N:mpr_conv_set_window_fwd_min_width=8" ...
+(NAME=value: attribute of ops; N:function=value: a knob of include/mpr_hip_debug.h, restored from its return value.)  Every setting is applied alone (all others at their defaults) and measured `reps` times, interleaved with the default."""
 import sys, time, yaml, torch
 sys.path.insert(0, '.')
 import bench
-from multimodal_plankton_recognition_amd import ops
+from multimodal_plankton_recognition_amd import ops, _native as N
 from multimodal_plankton_recognition_amd.model import MultiModel
 dev = torch.device('cuda', 0)
 card = yaml.safe_load(open(bench.CARD))
@@ -35,10 +35,16 @@ for rep in range(4):
         if s != 'default':
             for kv in s.split(','):
                 k, v = kv.split('=')
-                saved[k] = getattr(ops, k)
-                setattr(ops, k, eval(v))
+                if k.startswith('N:'):
+                    saved[k] = N.query(k[2:], int(v))
+                else:
+                    saved[k] = getattr(ops, k)
+                    setattr(ops, k, eval(v))
         res[s].append(timed())
         for k, v in saved.items():
-            setattr(ops, k, v)
+            if k.startswith('N:'):
+                N.query(k[2:], v)
+            else:
+                setattr(ops, k, v)
 for s in settings:
     print(f'{s:40s} ' + ' '.join(f'{t:6.3f}' for t in res[s]) + f'   mean {sum(res[s]) / len(res[s]):6.3f} ms/step', flush=True)

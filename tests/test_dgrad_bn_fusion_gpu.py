@@ -6,6 +6,18 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _window_kernel_on_narrow_maps():
+    """The maps of these tests are 6 to 12 pixels wide: keep their forward convolutions on the shifted-window kernel as
+    well (by default maps narrower than 8 pixels take the implicit GEMM: mpr_conv_set_window_fwd_min_width)."""
+    from multimodal_plankton_recognition_amd import _native as N
+    old = N.query('mpr_conv_set_window_fwd_min_width', 0)
+    yield
+    N.query('mpr_conv_set_window_fwd_min_width', old)
+
+
 DEV = 'cuda'
 
 

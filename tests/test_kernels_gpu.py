@@ -70,6 +70,8 @@ def igemm_path(request):
     thr = 1 << 30 if request.param == 'regs' else 0
     old_win = _native.query('mpr_conv_set_window', 1 if request.param == 'win' else 0)
     request.addfinalizer(lambda: _native.query('mpr_conv_set_window', old_win))
+    old_mw = _native.query('mpr_conv_set_window_fwd_min_width', 0)      # the window kernel on narrow maps too
+    request.addfinalizer(lambda: _native.query('mpr_conv_set_window_fwd_min_width', old_mw))
     old_ww = _native.query('mpr_conv_set_wgrad_window', 1 if request.param == 'win' else 0)
     request.addfinalizer(lambda: _native.query('mpr_conv_set_wgrad_window', old_ww))
     old = _native.query('mpr_conv_set_dma_min_rows', thr)
