@@ -1,9 +1,10 @@
 """Timeline of one traced step (rocprofv3 --kernel-trace CSV of scripts/prof_step.sh): per phase of the step, how long each
 queue is busy, and the intervals in which no big kernel (>= 256 workgroups) runs anywhere.
 usage: python scripts/step_timeline.py <tag>"""
-import csv, glob, sys
+import csv, glob, os, sys
 tag = sys.argv[1]
-rows = list(csv.DictReader(open(glob.glob(f'gpurun_out/prof_{tag}/*/*kernel_trace.csv')[0])))
+# (the merged gpurun_out/ keeps the traces of earlier runs: take the newest)
+rows = list(csv.DictReader(open(max(glob.glob(f'gpurun_out/prof_{tag}/*/*kernel_trace.csv'), key=os.path.getmtime))))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 sgd = [i for i, r in enumerate(rows) if 'sgd_multi' in r['Kernel_Name']]
 seg = rows[sgd[-2] + 1:sgd[-1] + 1]
