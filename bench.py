@@ -246,11 +246,11 @@ def main():
 
         fam = {'win_fwd': family([6], 'conv_win_kernel / conv_win_persist_kernel, forward (3x3 stride 1)', 'win_fwd'),
                'win_dgrad': family([7], 'conv_win_kernel, data gradient (+ fused skip add, ReLU mask, BatchNorm-backward sums)', 'win_dgrad'),
-               'dma_fwd_dgrad': family([0, 1], 'conv_igemm_dma_kernel (stride-2 3x3 and 1x1 convolutions, forward + data gradient)', 'dma_fwd_dgrad'),
+               'dma_fwd_dgrad': family([0, 1], 'conv_igemm_dma_kernel (stride-2 3x3 and 1x1 convolutions forward + data gradient, layer4 3x3 forward)', 'dma_fwd_dgrad'),
                'wgrad_win': family([8], 'conv_wgrad_win_kernel (3x3 stride 1 weight gradients)', 'wgrad_win'),
                'wgrad_dma': family([2], 'conv_wgrad_dma_kernel (other weight gradients)', 'wgrad_dma')}
-        dom = family([6, 7], 'conv_win_kernel (shifted-window implicit-GEMM conv: forward + data-gradient instantiations, 13 of '
-                             "ResNet-18's 20 convolutions, 80 % of its FLOPs)", 'win_fwd_dgrad')
+        dom = family([6, 7], 'conv_win_kernel (shifted-window implicit-GEMM conv: the forward passes of 10 and the data gradients '
+                             "of 13 of ResNet-18's 20 convolutions, about three quarters of its forward + data-gradient FLOPs)", 'win_fwd_dgrad')
         if dom['launches'] == 0:
             # cards without 3x3 / stride-1 convolutions (transformer encoders: every linear is a one-tap implicit GEMM)
             dom = family([0, 1], 'conv_igemm_dma_kernel (LDS-DMA implicit GEMM: the linears of the transformer encoders, forward + '

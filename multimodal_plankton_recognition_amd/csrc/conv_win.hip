@@ -1,6 +1,7 @@
 // Shifted-window implicit GEMM for 3x3 / stride 1 / pad 1 convolutions (forward and data gradient) -- the 13 "body"
 // convolutions of a ResNet-18 (timm BasicBlock conv1/conv2 behind src/image_encoder.py:24), which carry 80 % of its
-// FLOPs.
+// FLOPs.  (On maps narrower than 8 pixels the FORWARD pass takes conv_igemm.hip's 256 x 256 tile instead: the padded raster
+// below costs +31 % positions at 7 x 7, mpr_conv_set_window_fwd_min_width.)
 //
 // Why a second kernel: measured per-workgroup phase times (scripts/conv_phases.py) put the plain LDS-DMA implicit
 // GEMM (conv_igemm.hip) exactly on the CU's global->LDS fill rate (~73 GB/s per CU, MI355X guide "gather into LDS"):
