@@ -132,6 +132,16 @@ class _PackRegistry:
                 N.call('mpr_conv_pack_weights_multi', self.table, len(live))
                 self.event.record(self.stream)
             self.gen += 1
+            # the panels and the table were allocated on other streams: tell the allocator that this one uses them too (once
+            # per tensor), or memory freed with a dying model could be handed out again while the refresh still writes it
+            if getattr(self.table, '_mpr_on_pack_stream', None) is not self.stream:
+                self.table.record_stream(self.stream)
+                self.table._mpr_on_pack_stream = self.stream
+            for e in live:
+                for t in (e[2], e[3]):
+                    if t is not None and getattr(t, '_mpr_on_pack_stream', None) is not self.stream:
+                        t.record_stream(self.stream)
+                        t._mpr_on_pack_stream = self.stream
         else:
             N.call('mpr_conv_pack_weights_multi', self.table, len(live))
         for e in live:

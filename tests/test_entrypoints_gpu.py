@@ -112,10 +112,13 @@ def test_dp_step_world1_equals_single_gpu_step():
                 loss.backward()
                 opt.step()
             results.append((loss.item(), {k: v.detach().clone() for k, v in model.state_dict().items()}))
-        assert abs(results[0][0] - results[1][0]) < 1e-5
-        for k, v in results[0][1].items():
-            if v.is_floating_point():
-                assert torch.allclose(v, results[1][1][k], rtol=1e-4, atol=1e-6), k
+        assert abs(results[0][0] - results[1][0]) < 1e-5, (results[0][0], results[1][0])
+        # (every offender with its distance, not just the first key: a failure here must say whether it is summation noise
+        #  or a lost gradient)
+        off = {k: (float((v - results[1][1][k]).abs().max()), float(v.abs().max()))
+               for k, v in results[0][1].items()
+               if v.is_floating_point() and not torch.allclose(v, results[1][1][k], rtol=1e-4, atol=1e-6)}
+        assert not off, off
     finally:
         D.shutdown()
 
