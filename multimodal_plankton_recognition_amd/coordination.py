@@ -93,7 +93,8 @@ class _PairLossFn(torch.autograd.Function):
         N.call('mpr_clipf_bwd', uv, logit_scale.detach(), None if bias is None else bias.detach(), lse, lse, coef, uv, inv,
                a if beta else None, p if beta else None, 2.0 * beta / a.numel() if beta else 0.0, gout, da, dp, dls, db,
                ws, 1, 0, b, D, buckets)
-        return da, dp, dls, db, None, None
+        # (the two scalars go into the optimizer's gradient memory off the dependent chain when it owns some)
+        return da, dp, ops.accumulate_off_chain(logit_scale, dls), ops.accumulate_off_chain(bias, db), None, None
 
 
 def retrieval_top1(image_emb: Tensor, profile_emb: Tensor):

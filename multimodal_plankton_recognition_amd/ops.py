@@ -966,6 +966,39 @@ def linear_wgrad(dy, x, weight):
     return None
 
 
+def accumulate_off_chain(param, g):
+    """Gradient of a small parameter computed inside a backward Function (the losses' logit_scale / bias): with
+    optimizer-owned gradient memory it is added there on the weight-gradient side stream and None is returned (autograd's
+    AccumulateGrad would put a 5-us add kernel + its dispatch into the dependent chain of the junction, where the chip is
+    idle and every microsecond counts); otherwise `g` comes back for autograd."""
+    tgt = grad_target(param)
+    if tgt is None or g is None:
+        return g
+    if ASYNC_WGRAD:
+        cur, side = _wgrad_stream(g.device.index)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            tgt.add_(g.reshape(tgt.shape))
+        _note_arena_stream(g.device.index, side)
+        g.record_stream(side)
+    else:
+        tgt.add_(g.reshape(tgt.shape))
+    return None
+
+
+_root_grads = {}
+
+
+def backward(loss):
+    """loss.backward() with a cached root gradient of one (torch fills a fresh ones_like(loss) per call: a 5-us kernel in
+    front of the first backward kernel)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _root_grads.get(key)
+    if one is None:
+        one = _root_grads[key] = torch.ones_like(loss)
+    torch.autograd.backward(loss, one)
+
+
 def tail_fwd(feat, meta, denom, p_drop, seed):
     B, Fd = feat.shape
     Mm = 0 if meta is None else meta.shape[1]

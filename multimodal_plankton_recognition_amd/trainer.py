@@ -12,6 +12,8 @@ import re
 
 import torch
 
+from . import ops
+
 
 class TensorBoardLogger:
     """Directory layout of lightning's TensorBoardLogger; metrics go to metrics.jsonl (tensorboard is absent)."""
@@ -178,7 +180,7 @@ class Trainer:
                     self.global_step += 1
                 else:
                     loss = model.training_step(self._to_device(batch), i)
-                    (loss / self.accumulate if self.accumulate > 1 else loss).backward()
+                    ops.backward(loss / self.accumulate if self.accumulate > 1 else loss)
                     pending += 1
                     if pending == self.accumulate:
                         self.optimizer.step()
