@@ -103,6 +103,7 @@ def test_dp_step_world1_equals_single_gpu_step():
         for dp in (False, True):
             torch.manual_seed(3)
             model = MultiModel(**cfg).cuda().train()
+            init = {k: v.detach().clone() for k, v in model.state_dict().items()}
             opt = model.configure_optimizers()
             if dp:
                 loss = D.DataParallelStep(model, opt, 1).step(batch)
@@ -111,13 +112,23 @@ def test_dp_step_world1_equals_single_gpu_step():
                 loss = model.training_step(batch, 0)
                 loss.backward()
                 opt.step()
-            results.append((loss.item(), {k: v.detach().clone() for k, v in model.state_dict().items()}))
-        assert abs(results[0][0] - results[1][0]) < 1e-5, (results[0][0], results[1][0])
-        # (every offender with its distance, not just the first key: a failure here must say whether it is summation noise
-        #  or a lost gradient)
-        off = {k: (float((v - results[1][1][k]).abs().max()), float(v.abs().max()))
-               for k, v in results[0][1].items()
-               if v.is_floating_point() and not torch.allclose(v, results[1][1][k], rtol=1e-4, atol=1e-6)}
+            results.append((loss.item(), {k: v.detach().clone() for k, v in model.state_dict().items()}, init))
+        assert abs(results[0][0] - results[1][0]) < 1e-4, (results[0][0], results[1][0])
+        # Two executions of one step are not bit-identical (the stem's statistics and weight gradient are summed by LDS /
+        # fp32 atomics in wave order; one ulp in a BatchNorm coefficient flips a few bf16 roundings downstream), so the
+        # comparison is on what the step DID to every tensor: a gradient that never arrived or arrived twice changes its
+        # update by O(1), summation noise by far less than the 2 % allowed here.  Every offender is reported.
+        off = {}
+        for k, v in results[0][1].items():
+            if not v.is_floating_point():
+                assert torch.equal(v, results[1][1][k]), k
+                continue
+            assert torch.equal(results[0][2][k], results[1][2][k]), k                # same initialisation
+            d0, d1 = (v - results[0][2][k]).double(), (results[1][1][k] - results[1][2][k]).double()
+            scale = float(d0.norm())
+            err = float((d0 - d1).norm())
+            if err > 2e-2 * scale + 1e-9:
+                off[k] = (err, scale)
         assert not off, off
     finally:
         D.shutdown()
