@@ -430,15 +430,31 @@ __global__ __launch_bounds__(256) void clipf_norm_bwd_kernel(const float* __rest
   float dot = 0.f;
   const bool inreg = D <= 1024;
   if (inreg) {
+    // strip-major: the (up to 16) loads of one strip are independent and go out together -- with the strips innermost every
+    // element waited for its nchunk loads one after the other (this kernel runs alone on the chip, in the junction of the
+    // step).  Same order of additions per element.
+#pragma unroll
+    for (int k = 0; k < 16; ++k) du[k] = 0.f;
+    for (int t0 = 0; t0 < nchunk; t0 += 4) {             // four strips of loads in flight (the kernel is latency-bound)
+      float tmp[4][16];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* pt = part + (size_t)(t0 + u) * b * D;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int d = lane + 64 * k;
+          tmp[u][k] = (t0 + u < nchunk && d < D) ? pt[d] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) du[k] += tmp[u][k];      // (+ 0.f for the strips / columns that do not exist)
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int d = lane + 64 * k;
-      float s = 0.f;
-      if (d < D) {
-        for (int t = 0; t < nchunk; ++t) s += part[(size_t)t * b * D + d];
-        dot = fmaf(ur[d], s, dot);
-      }
-      du[k] = s;
+      if (d < D) dot = fmaf(ur[d], du[k], dot);
     }
   } else {
     for (int d = lane; d < D; d += 64) {
