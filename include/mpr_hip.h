@@ -227,6 +227,49 @@ int mpr_global_avgpool_bwd(const float* dy, void* dx, int B, int L, int C, void*
 int mpr_global_maxpool_fwd(const void* x, float* y, int* idx, int B, int L, int C, void* stream);
 int mpr_global_maxpool_bwd(const float* dy, const int* idx, void* dx, int B, int L, int C, void* stream);
 
+/* ---- fp32 PARITY path of the conv stacks (conv_f32.hip; trainer / card `precision: 32`, as Lightning's flag in
+ *      scripts/train_multi.py:99-104 selects fp32 in the reference): fp32 channels-last feature maps, fp32 filters addressed
+ *      through element strides (sk, sc, sr, ss) of their logical [K,C,R,S] shape, every product on the exact-fp32 MFMA,
+ *      statistics in double, no atomics (bitwise reproducible).  Same reference call sites as the bf16 entry points above:
+ *      nn.Conv2d / nn.Conv1d, nn.BatchNorm, nn.MaxPool, global pooling of timm's ResNet (src/image_encoder.py:16,24) and of
+ *      ProfileCNN / _BasicBlock (src/profile_encoder.py:111-240). */
+int mpr_f32_conv_fwd(const float* x, const float* w, long long sk, long long sc, long long sr, long long ss, float* y, int B,
+                     int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream);
+int mpr_f32_conv_dgrad(const float* dy, const float* w, long long sk, long long sc, long long sr, long long ss, float* dx,
+                       const float* add /* may be NULL */, int B, int H, int W, int C, int K, int R, int S, int sh, int sw,
+                       int ph, int pw, void* stream);
+/* floats of scratch mpr_f32_conv_wgrad needs for this geometry (partial tiles of the split over pixels; 0: none) */
+long long mpr_f32_conv_wgrad_scratch_floats(int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw);
+/* dw (strides as the filter's) = or += the weight gradient */
+int mpr_f32_conv_wgrad(const float* x, const float* dy, float* dw, long long sk, long long sc, long long sr, long long ss,
+                       int accumulate, float* scratch, long long scratch_floats, int B, int H, int W, int C, int K, int R,
+                       int S, int sh, int sw, int ph, int pw, void* stream);
+/* train-mode BatchNorm on fp32 maps [rows][C]: partial rows of 2*C DOUBLES (sum, sum of squares | sum dz, sum dz*xhat) */
+int mpr_f32_bn_parts(long long rows, int C);
+int mpr_f32_bn_stats(const float* x, void* partial, long long rows, int C, void* stream);
+int mpr_f32_bn_finalize(const void* partial, int nparts, long long count, const float* gamma, const float* beta,
+                        float* running_mean /* may be NULL */, float* running_var, float momentum, float eps, float* scale,
+                        float* shift, float* mean, float* invstd, int C, void* stream);
+int mpr_f32_bn_apply(const float* x, const float* scale, const float* shift, const float* residual /* may be NULL */,
+                     int relu, float* y, long long rows, int C, void* stream);
+/* dz = dy * (mask_y > 0) (mask_y NULL: dz = dy) */
+int mpr_f32_bn_bwd_reduce(const float* dy, const float* mask_y, const float* x, const float* mean, const float* invstd,
+                          void* partial, long long rows, int C, void* stream);
+/* count == 0: the layer ran on its running statistics (eval): dx = gamma * invstd * dz */
+int mpr_f32_bn_bwd_finalize(const void* partial, int nparts, long long count, const float* gamma, const float* mean,
+                            const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef /* [3][C] */,
+                            int C, void* stream);
+int mpr_f32_bn_bwd_apply(const float* dy, const float* mask_y, const float* x, const float* coef, float* dx,
+                         float* dz_out /* may be NULL */, long long rows, int C, void* stream);
+/* idx: int32 linear input position ih*W+iw of the first maximum in torch's scan order */
+int mpr_f32_maxpool_fwd(const float* x, float* y, int* idx, int B, int H, int W, int C, int RH, int RW, int SH, int SW, int PH,
+                        int PW, void* stream);
+int mpr_f32_maxpool_bwd(const float* dy, const int* idx, float* dx, int B, int H, int W, int C, int RH, int RW, int SH, int SW,
+                        int PH, int PW, void* stream);
+/* [B][L][C] -> [B][C]; mode 0 = mean, 1 = max (+ idx: first arg-max position) */
+int mpr_f32_global_pool_fwd(const float* x, float* y, int* idx /* mode 1 */, int B, int L, int C, int mode, void* stream);
+int mpr_f32_global_pool_bwd(const float* dy, const int* idx, float* dx, int B, int L, int C, int mode, void* stream);
+
 /* ---- exact-fp32 batched GEMM: C = alpha*op(A)*op(B) (+bias) + beta*C --------------------------
  * nn.Linear(bias=False) projections (src/model.py:31-32,40-41,80-82), classifier heads
  * (src/model.py:164,316), similarity matrix and its gradient products (src/coordination.py:38,89). */

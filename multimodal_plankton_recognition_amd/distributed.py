@@ -62,12 +62,19 @@ def max_over_ranks(value: float) -> float:
 
 
 class Comm:
-    """The two collectives the path needs."""
+    """The collectives the path needs.  `collective` selects how a slice of the gradient buffer is summed over the ranks:
+    'all_reduce' (RCCL's own choice of algorithm) or 'rs_ag' -- an explicit reduce-scatter into this rank's 1/world share
+    followed by an all-gather of the shares, both in place (SURVEY 8e "Collectives (4)": on point-to-point xGMI the two
+    halves are the direct, per-link-bound form of the ring all-reduce; kept switchable, MPR_DP_COLLECTIVE, until a node
+    run has priced one against the other)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, collective=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.collective = collective or os.environ.get('MPR_DP_COLLECTIVE', 'all_reduce')
+        if self.collective not in ('all_reduce', 'rs_ag'):
+            raise ValueError(f"Comm: collective must be 'all_reduce' or 'rs_ag' (got {self.collective!r})")
 
     def _staged(self, x):
         # gloo rehearsal with device tensors (several ranks sharing one GPU): stage through the host
@@ -102,6 +109,31 @@ class Comm:
         """Enqueue the all-reduce behind torch's CURRENT stream and return the work handle (work.wait() makes the then
         current stream wait for it)."""
         return dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def sum_grads(self, x, async_op=False):
+        """Sum a contiguous 1-D slice of the gradient buffer over the ranks, in place, by the configured collective.
+        -> list of work handles (async_op) or x."""
+        works = []
+        n = x.numel()
+        m = n // self.world * self.world if self.collective == 'rs_ag' else 0
+        if m and self.world > 1:
+            if self._staged(x):
+                h = x[:m].cpu()
+                mine = h.view(self.world, -1)[self.rank].clone()
+                dist.reduce_scatter_tensor(mine, h, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_gather_into_tensor(h, mine, group=self.group)
+                x[:m].copy_(h)
+            else:
+                mine = x[:m].view(self.world, -1)[self.rank]          # this rank's share, reduced in place
+                w1 = dist.reduce_scatter_tensor(mine, x[:m], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                w2 = dist.all_gather_into_tensor(x[:m], mine, group=self.group, async_op=async_op)
+                works += [w1, w2] if async_op else []
+        if m < n:                                                    # (rs_ag: the < world elements that do not divide)
+            if async_op:
+                works.append(self.all_reduce_sum_async(x[m:]))
+            else:
+                self.all_reduce_sum(x[m:])
+        return works if async_op else x
 
 
 # ------------------------------------------------------------------------------------------------ math back end
@@ -185,7 +217,7 @@ def _global_loss(comm, share, mse_share):
     return comm.all_reduce_sum(local.reshape(1).clone()).reshape(())
 
 
-def dp_siglip(image_emb, profile_emb, logit_scale, bias, comm, math, beta=0.0):
+def dp_siglip(image_emb, profile_emb, logit_scale, bias, comm, math, beta=0.0, grad_scale=1.0, want_grad=True):
     """Sharded SigLIP loss (src/coordination.py:76-95 over the GLOBAL batch, buckets = 1; + beta * MSE for SigLIPPlus).
 
     Every (image i, profile j) pair is owned by the rank that owns row i: the loss and the parameter gradients are sums of
@@ -199,12 +231,14 @@ def dp_siglip(image_emb, profile_emb, logit_scale, bias, comm, math, beta=0.0):
     gathered = comm.all_gather(uv)                                   # [world, 2, b, D]
     share = math.siglip_fwd(gathered, logit_scale, bias, comm.rank, 1.0 / n)
     mse, mse_coef = _mse_term(a32, p32, beta, n, math)
-    d_img, d_prof, dls, db = math.siglip_bwd(gathered, logit_scale, bias, comm.rank, 1.0 / n, uv, inv,
-                                             a32 if beta else None, p32 if beta else None, mse_coef)
+    if not want_grad:
+        return _global_loss(comm, share, mse), None, None, None, None
+    d_img, d_prof, dls, db = math.siglip_bwd(gathered, logit_scale, bias, comm.rank, grad_scale / n, uv, inv,
+                                             a32 if beta else None, p32 if beta else None, mse_coef * grad_scale)
     return _global_loss(comm, share, mse), d_img, d_prof, dls, db
 
 
-def dp_clip(image_emb, profile_emb, logit_scale, comm, math, beta=0.0):
+def dp_clip(image_emb, profile_emb, logit_scale, comm, math, beta=0.0, grad_scale=1.0, want_grad=True):
     """Sharded CLIP loss (src/coordination.py:26-47 over the GLOBAL batch, buckets = 1; + beta * MSE for CLIPPlus).
 
     Returns (loss [global value, identical on every rank], dL/d image_emb, dL/d profile_emb,
@@ -217,10 +251,13 @@ def dp_clip(image_emb, profile_emb, logit_scale, comm, math, beta=0.0):
     # lse[0]: my images over all profiles, lse[1]: my profiles over all images; the softmax over the other axis of a
     # row block needs every rank's vector of the other role
     lse, share = math.clip_fwd(gathered, logit_scale, comm.rank, 1.0 / (2.0 * n))
-    lse_all = comm.all_gather(lse)                                   # [world, 2, b]
     mse, mse_coef = _mse_term(a32, p32, beta, n, math)
-    d_img, d_prof, dls = math.clip_bwd(gathered, logit_scale, lse, lse_all, comm.rank, 1.0 / (2.0 * n), uv, inv,
-                                       a32 if beta else None, p32 if beta else None, mse_coef)
+    if not want_grad:                                                # validation: the value only
+        return _global_loss(comm, share, mse), None, None, None
+    lse_all = comm.all_gather(lse)                                   # [world, 2, b]
+    # grad_scale: 1 / accumulate_grad_batches (the VALUE returned stays the unscaled global-batch loss)
+    d_img, d_prof, dls = math.clip_bwd(gathered, logit_scale, lse, lse_all, comm.rank, grad_scale / (2.0 * n), uv, inv,
+                                       a32 if beta else None, p32 if beta else None, mse_coef * grad_scale)
     return _global_loss(comm, share, mse), d_img, d_prof, dls
 
 
@@ -299,8 +336,14 @@ class GradBuckets:
             for j in [j for j in self.pending if j != k]:
                 self._launch(j)
                 self.pending.remove(j)
-        if k is None or self.sent[k]:
+        if k is None:
             return
+        if self.sent[k]:
+            # a parameter that receives gradient from a second backward node (a shared / tied weight, a module called twice)
+            # would be written while or after its slice is being reduced: ranks would apply different gradients, silently
+            raise RuntimeError('GradBuckets: a gradient was reported for a parameter whose bucket has already been sent to '
+                               'the all-reduce (a parameter used by more than one backward node?); set MPR_DP_BUCKETS=0 for '
+                               'this model (one all-reduce after backward)')
         self.count[k].add(id(param))
         if self.comm.overlaps:
             cur = torch.cuda.current_stream()          # (autograd runs a node on the stream of its forward: the two encoders
@@ -322,7 +365,7 @@ class GradBuckets:
             if sd is not None and sd is not carrier:
                 carrier.wait_stream(sd)
         with torch.cuda.stream(carrier):
-            self.works.append(self.comm.all_reduce_sum_async(self.opt.flat_grad[lo:hi]))
+            self.works += self.comm.sum_grads(self.opt.flat_grad[lo:hi], async_op=True)
         self.sent[k] = True
 
     def finish(self):
@@ -341,7 +384,7 @@ class GradBuckets:
         g = self.opt.flat_grad
         for k, b in enumerate(self.buckets):
             if not self.sent[k]:
-                self.comm.all_reduce_sum(g[b[0]:b[1]])
+                self.comm.sum_grads(g[b[0]:b[1]])
         for lo, hi in self.rest:
             self.comm.all_reduce_sum(g[lo:hi])
         for w in self.works:
@@ -390,6 +433,8 @@ class DataParallelStep:
         self.comm = comm or Comm()
         self.math = math or HipClipMath()
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self.steps_done, self.verified = 0, []
+        self.verify_steps = int(os.environ.get('MPR_DP_VERIFY_STEPS', '2'))
         self._flat = None
         self._views = None
         self.buckets = None
@@ -411,39 +456,66 @@ class DataParallelStep:
             self._views = views
         return self._flat, self._views
 
-    def step(self, batch):
-        model = self.model
-        self.opt.zero_grad()
-        if batch.get('buckets', 1) != 1:
-            raise NotImplementedError('data-parallel step: buckets must be 1 (the global batch is one bucket)')
-        if self.buckets is not None:
-            self.buckets.begin()
-        emb = model.encode(**batch)
+    def _sharded_loss(self, emb, grad_scale=1.0, want_grad=True):
         core = self.core
         if self.kind == 'clip':
             loss, d_img, d_prof, dls = dp_clip(emb['image_emb'], emb['profile_emb'], core.logit_scale, self.comm,
-                                               self.math, self.beta)
-            pgrads = [(core.logit_scale, dls)]
-        else:
-            loss, d_img, d_prof, dls, db = dp_siglip(emb['image_emb'], emb['profile_emb'], core.logit_scale, core.bias,
-                                                     self.comm, self.math, self.beta)
-            pgrads = [(core.logit_scale, dls), (core.bias, db)]
+                                               self.math, self.beta, grad_scale, want_grad)
+            return loss, d_img, d_prof, [(core.logit_scale, dls)]
+        loss, d_img, d_prof, dls, db = dp_siglip(emb['image_emb'], emb['profile_emb'], core.logit_scale, core.bias,
+                                                 self.comm, self.math, self.beta, grad_scale, want_grad)
+        return loss, d_img, d_prof, [(core.logit_scale, dls), (core.bias, db)]
+
+    def validation_step(self, batch):
+        """The GLOBAL-batch loss of one validation batch (the ranks' shards of it together are one contrastive bucket, as in
+        the training step): the same number on every rank, comparable with a single-GPU run at the same global batch.
+        Call under torch.no_grad() with the model in eval mode."""
+        if batch.get('buckets', 1) != 1:
+            raise NotImplementedError('data-parallel validation: buckets must be 1 (the global batch is one bucket)')
+        emb = self.model.encode(**batch)
+        loss = self._sharded_loss(emb, want_grad=False)[0]
+        self.model.valid_loss.append(loss.detach())
+        return loss
+
+    def step(self, batch, micro=0, of=1):
+        """One micro-batch of an optimisation step; `of` = accumulate_grad_batches (Lightning semantics,
+        scripts/train_multi.py:99-104 of the reference: every micro-batch's loss is divided by `of`, the optimizer steps
+        after the last one).  Every micro-batch's loss is the GLOBAL contrastive loss over the ranks' shards of it (two
+        small all-gathers each); the gradient buckets cross the links once, during the LAST micro-batch's backward."""
+        model = self.model
+        first, last = micro == 0, micro == of - 1
+        if first:
+            self.opt.zero_grad()
+        if batch.get('buckets', 1) != 1:
+            raise NotImplementedError('data-parallel step: buckets must be 1 (the global batch is one bucket)')
+        if self.buckets is not None and last:
+            self.buckets.begin()
+        emb = model.encode(**batch)
+        loss, d_img, d_prof, pgrads = self._sharded_loss(emb, grad_scale=1.0 / of)
         torch.autograd.backward([emb['image_emb'], emb['profile_emb']], [d_img, d_prof])
         arena = getattr(self.opt, 'flat_grad', None)
-        if arena is not None and all(getattr(p, '_mpr_grad', None) is p.grad for p, _ in pgrads):
+        fused = arena is not None and all(getattr(p, '_mpr_grad', None) is not None for p, _ in pgrads)
+        if fused:
             # FusedSGD: every gradient already sits in the optimizer's flat buffer (the fused backward Functions
             # accumulate into it) -- ONE all-reduce of that buffer, no gather copies
             for p, g in pgrads:
+                if p.grad is not p._mpr_grad:
+                    p.grad = p._mpr_grad
                 p.grad.add_(g.reshape(p.shape))
                 p._mpr_touched = True
+        else:
+            for p, g in pgrads:
+                p.grad = g.reshape(p.shape) if p.grad is None or first else p.grad + g.reshape(p.shape)
+        model.train_loss.append(loss.detach())
+        if not last:
+            return loss
+        if fused:
             if self.buckets is not None:
                 self.buckets.finish()          # (layer4 / layer3 / ... went out during backward; the rest goes now)
             else:
                 ops.join_gradient_streams()
-                self.comm.all_reduce_sum(arena)
+                self.comm.sum_grads(arena)
         else:
-            for p, g in pgrads:
-                p.grad = g.reshape(p.shape)
             flat, views = self._flat_views()
             # a parameter that received no gradient keeps grad None (the optimizer then skips it, weight decay included,
             # as in the single-process step); the graph is the same on every rank, so "has a gradient" is too
@@ -452,9 +524,62 @@ class DataParallelStep:
             live = [(v, p.grad) for v, p, h in zip(views, self.params, has) if h]
             if live:
                 torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
-            self.comm.all_reduce_sum(flat)
+            self.comm.sum_grads(flat)
             for p, v, h in zip(self.params, views, has):
                 p.grad = v if h else None
         self.opt.step()
-        model.train_loss.append(loss.detach())
+        self.steps_done += 1
+        if self.steps_done <= self.verify_steps:
+            self.verify_replicas()
         return loss
+
+    # ---- replicas must stay bit-identical: checked on the hardware in the first steps -------------------------------
+    def _replica_fingerprint(self):
+        parts = [p.detach().double().sum() for p in self.params] + [p.detach().double().abs().sum() for p in self.params]
+        return torch.stack(parts)
+
+    def verify_replicas(self):
+        """After an optimizer step every rank must hold bit-identical parameters (same initial values, same summed
+        gradients).  A gradient written after its bucket went to the all-reduce, or a collective that ran ahead of a
+        producer, shows up as ranks that differ: compared here (MIN and MAX over the ranks of per-parameter sums, two tiny
+        all-reduces) in the first `verify_steps` steps of a run -- the overlap bookkeeping is then verified on the actual
+        machine, under RCCL, before training relies on it.  On a mismatch the bucketed overlap is switched off (one
+        reduction after backward), the replicas are re-synchronised from rank 0 and a warning is printed; it never passes
+        silently."""
+        fp = self._replica_fingerprint()
+        if self.comm._staged(fp):
+            fp = fp.cpu()
+        lo, hi = fp.clone(), fp.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.comm.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.comm.group)
+        same = bool(torch.equal(lo, hi))
+        self.verified.append(same)
+        if not same:
+            import warnings
+            bad = int((lo != hi).sum())
+            warnings.warn(f'data-parallel step {self.steps_done}: replicas differ after the optimizer step ({bad} parameter '
+                          f'sums): switching the bucketed gradient overlap OFF and re-synchronising from rank 0')
+            if self.buckets is not None:
+                self.buckets.close()
+                self.buckets = None
+            broadcast_module(self.model, self.comm)
+            self.verify_steps = self.steps_done + 2
+        return same
+
+
+def broadcast_module(model, comm=None, src=0):
+    """Every parameter and buffer of `model` := rank `src`'s (replica equality then does not rest on the seed alone)."""
+    group = comm.group if comm is not None else None
+    staged = comm._staged if comm is not None else (lambda t: t.is_cuda and dist.get_backend(group) == 'gloo')
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            if staged(t):
+                h = t.detach().cpu()
+                dist.broadcast(h, src=src, group=group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t.detach(), src=src, group=group)
+    if hasattr(ops, 'pack_registry'):
+        for p in model.parameters():               # bf16 filter panels are caches of the fp32 masters: rebuild on next use
+            if hasattr(p, '_mpr_packed'):
+                del p._mpr_packed

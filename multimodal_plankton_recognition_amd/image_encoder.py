@@ -49,13 +49,17 @@ class ResNetBackbone(nn.Module):
         self._chain = chain_blocks(blk for li in range(1, 5) for blk in getattr(self, f'layer{li}'))
 
     def forward_features(self, image: Tensor) -> Tensor:
-        """fp32 [B, in_chans, H, W] -> channels-last bf16 [B, H/32, W/32, 512]."""
+        """fp32 [B, in_chans, H, W] -> channels-last bf16 (fp32 under `precision: 32`) [B, H/32, W/32, 512]."""
         B, C, H, W = image.shape
         x = image.float()
         x = x.reshape(B, H, W, 1) if C == 1 else x.permute(0, 2, 3, 1)
         x = x.contiguous()
         self._chain.clear()
-        out = StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
+        from . import layers_f32
+        if layers_f32.conv_f32():            # `precision: 32`: fp32 maps on the exact-fp32 kernels (parity mode)
+            out = layers_f32.stem(self, x)
+        else:
+            out = StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
         for li in range(1, 5):
             for blk in getattr(self, f'layer{li}'):
                 out = blk(out)

@@ -240,6 +240,9 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         ds = self.downsample
+        if x.dtype == torch.float32:          # fp32 parity mode (`precision: 32`): unfused exact-fp32 kernels, layers_f32.py
+            from . import layers_f32
+            return layers_f32.basic_block(self, x)
         return BasicBlockFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
                                   self.bn2.weight, self.bn2.bias,
                                   ds[0].weight if ds is not None else None,
@@ -265,17 +268,25 @@ class PoolTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, fmap, meta, mode, denom, p_drop):
-        feat, idx = ops.global_pool_fwd(fmap, mode)
+        f32 = fmap.dtype == torch.float32     # fp32 parity mode: fp32 feature map (layers_f32.py)
+        if f32:
+            from . import layers_f32
+            feat, idx = layers_f32.global_pool_fwd(fmap, mode)
+        else:
+            feat, idx = ops.global_pool_fwd(fmap, mode)
         out, mask = ops.tail_fwd(feat, meta, denom, p_drop, next_seed() if p_drop > 0 else 0)
         ctx.save_for_backward(idx, mask)
-        ctx.cfg = (mode, p_drop, feat.shape[1], fmap.shape)
+        ctx.cfg = (mode, p_drop, feat.shape[1], fmap.shape, f32)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         idx, mask = ctx.saved_tensors
-        mode, p_drop, Fd, shape = ctx.cfg
+        mode, p_drop, Fd, shape, f32 = ctx.cfg
         dfeat = ops.tail_bwd(dout.contiguous(), mask, p_drop, Fd)
+        if f32:
+            from . import layers_f32
+            return layers_f32.global_pool_bwd(dfeat, idx, shape, mode), None, None, None, None
         return ops.global_pool_bwd(dfeat, idx, shape, mode), None, None, None, None
 
 

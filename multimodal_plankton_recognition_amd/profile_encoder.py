@@ -59,7 +59,11 @@ class ProfileCNN(nn.Module):
     def forward_features(self, profile: Tensor) -> Tensor:
         """-> channels-last bf16 feature map [B, L/32, 8*base] (the reference returns [B, C, L])."""
         x = profile.contiguous().float()
-        out = StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
+        from . import layers_f32
+        if layers_f32.conv_f32():            # `precision: 32`: fp32 maps on the exact-fp32 kernels (parity mode)
+            out = layers_f32.stem(self, x)
+        else:
+            out = StemFn.apply(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 out = blk(out)

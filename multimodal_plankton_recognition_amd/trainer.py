@@ -112,12 +112,14 @@ class Trainer:
         self.check_val_every_n_epoch = check_val_every_n_epoch or 1
         self.max_steps = max_steps
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
-        # conv stacks: always bf16 storage / fp32 accumulate; transformer stacks: exact fp32 unless the card asks for
-        # mixed precision ('16-mixed' / 'bf16-mixed'), then bf16 GEMM operands + fused attention (transformer_mixed.py)
+        # conv stacks: bf16 storage / fp32 accumulate unless the card asks for `precision: 32` (fp32 maps on the exact-fp32
+        # kernels: the parity mode, layers_f32.py); transformer stacks: exact fp32 unless the card asks for mixed precision
+        # ('16-mixed' / 'bf16-mixed'), then bf16 GEMM operands + fused attention (transformer_mixed.py)
         self.precision = precision
         if precision is not None:
-            from . import transformer
+            from . import layers_f32, transformer
             transformer.set_precision(precision)
+            layers_f32.set_conv_precision(precision)
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         self.current_epoch, self.global_step, self.should_stop = 0, 0, False
         self.optimizer = None
