@@ -546,6 +546,8 @@ class DataParallelStep:
         machine, under RCCL, before training relies on it.  On a mismatch the bucketed overlap is switched off (one
         reduction after backward), the replicas are re-synchronised from rank 0 and a warning is printed; it never passes
         silently."""
+        if self.comm.world < 2:
+            return True
         fp = self._replica_fingerprint()
         if self.comm._staged(fp):
             fp = fp.cpu()

@@ -808,6 +808,17 @@ class BlockChain:
         self.notes.clear()
         self.sums.clear()
 
+    # The entries are non-leaf tensors of ONE forward / backward pass: a copy or a pickle of the owning module
+    # (copy.deepcopy(model), torch.save(model)) gets an EMPTY table -- the blocks of the copy share the one new object
+    # through deepcopy's memo, exactly as the originals share this one.
+    def __deepcopy__(self, memo):
+        new = BlockChain()
+        memo[id(self)] = new
+        return new
+
+    def __getstate__(self):
+        return {'notes': {}, 'sums': {}}
+
     def note_bn2(self, out, x2, st2):
         if DGRAD_BN_FUSION:
             self.notes[out.data_ptr()] = (out, x2, st2)

@@ -55,6 +55,10 @@ class ModelCheckpoint:
         ckpt_dir = os.path.join(trainer.logger.log_dir, 'checkpoints')
         os.makedirs(ckpt_dir, exist_ok=True)
         path = os.path.join(ckpt_dir, self.format_name(trainer.current_epoch, metrics))
+        v = 0
+        while os.path.exists(path):          # a second validation run in one epoch (val_check_interval): lightning's -vN suffix
+            v += 1
+            path = os.path.join(ckpt_dir, self.format_name(trainer.current_epoch, metrics)[:-5] + f'-v{v}.ckpt')
         torch.save({'state_dict': model.state_dict(), 'hyper_parameters': getattr(model, 'hparams', {}),
                     'epoch': trainer.current_epoch, 'global_step': trainer.global_step,
                     'optimizer_states': [trainer.optimizer.state_dict()] if trainer.optimizer else []}, path)
@@ -98,9 +102,11 @@ def load_from_checkpoint(model_cls, path, map_location='cpu', **override):
 class Trainer:
     """fit() also drives data-parallel training (the reference is single-GPU): launched under torchrun
     (WORLD_SIZE > 1, one process per GPU) every rank runs this loop on ITS shard of each global batch through
-    distributed.DataParallelStep -- global contrastive loss, bucketed gradient all-reduce over RCCL -- validation losses
-    are averaged over the ranks (so checkpointing and early stopping decide identically everywhere), and only rank 0
-    writes logs and checkpoints.  The loaders must shard the data (train_multi.py: DistributedSampler)."""
+    distributed.DataParallelStep -- global contrastive loss, bucketed gradient all-reduce over RCCL, gradient accumulation
+    with one reduction per optimizer step -- validation computes the same GLOBAL-batch contrastive loss (every rank logs
+    the same number: checkpointing and early stopping decide identically everywhere), and only rank 0 writes logs and
+    checkpoints.  Parameters and buffers are broadcast from rank 0 before the first step.  The loaders must shard the data
+    (train_multi.py: DistributedSampler)."""
 
     def __init__(self, logger=None, callbacks=(), max_epochs=1000, min_epochs=0, accumulate_grad_batches=1,
                  precision=None, val_check_interval=None, check_val_every_n_epoch=1, log_every_n_steps=50,
@@ -110,6 +116,8 @@ class Trainer:
         self.max_epochs, self.min_epochs = max_epochs, min_epochs or 0
         self.accumulate = max(1, int(accumulate_grad_batches or 1))
         self.check_val_every_n_epoch = check_val_every_n_epoch or 1
+        self.val_check_interval = val_check_interval
+        self.dp_global_validation = False
         self.max_steps = max_steps
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         # conv stacks: bf16 storage / fp32 accumulate unless the card asks for `precision: 32` (fp32 maps on the exact-fp32
@@ -152,6 +160,51 @@ class Trainer:
         batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
         return self.batch_transform(batch, training) if self.batch_transform is not None else batch
 
+    def _val_interval(self, train_loader):
+        """Lightning's `val_check_interval` (scripts/train_multi.py:103 of the reference passes the card's value through):
+        a float in (0, 1] = that fraction of a training epoch, an int = that many training batches; None / 1.0 = once at
+        the end of the epoch.  -> number of training batches between validation runs, or None for end-of-epoch only."""
+        v = self.val_check_interval
+        if v is None or (isinstance(v, float) and v == 1.0):
+            return None
+        if isinstance(v, bool) or not isinstance(v, (int, float)):
+            raise ValueError(f'val_check_interval must be an int or a float (got {v!r})')
+        if isinstance(v, int):
+            if v < 1:
+                raise ValueError(f'val_check_interval (int) must be >= 1 (got {v})')
+            n = len(train_loader) if hasattr(train_loader, '__len__') else None
+            if n is not None and self.limit_train_batches is not None:
+                n = min(n, int(self.limit_train_batches))
+            if n is not None and v > n:
+                raise ValueError(f'val_check_interval ({v}) must be less than or equal to the number of training batches ({n})')
+            return v
+        if not 0.0 < v <= 1.0:
+            raise ValueError(f'val_check_interval (float) must be in (0, 1] (got {v})')
+        if not hasattr(train_loader, '__len__'):
+            raise ValueError('a fractional val_check_interval needs a training loader with a length')
+        n = len(train_loader)
+        if self.limit_train_batches is not None:
+            n = min(n, int(self.limit_train_batches))
+        return max(1, int(n * v))
+
+    def _validate(self, model, valid_loader, stepper):
+        model.eval()
+        with torch.no_grad():
+            for i, batch in enumerate(valid_loader):
+                if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                    break
+                batch = self._to_device(batch, training=False)
+                if stepper is not None and self.dp_global_validation:
+                    batch['buckets'] = 1              # the ranks' shards of a validation batch = one global bucket
+                    stepper.validation_step(batch)
+                else:
+                    model.validation_step(batch, i)
+        model.on_validation_epoch_end()
+        for cb in self.callbacks:
+            if self.is_global_zero or not isinstance(cb, ModelCheckpoint):     # checkpoints: rank 0 only
+                cb.on_validation_end(self, model, self.callback_metrics)
+        model.train()
+
     def fit(self, model, train_loader, valid_loader=None):
         model.trainer = self
         model.to(self.device)
@@ -160,11 +213,14 @@ class Trainer:
         if self.world > 1:
             from . import distributed as D
             D.init(self.device)
-            if self.accumulate > 1:
-                raise NotImplementedError('data-parallel training: accumulate_grad_batches must be 1 (one global batch = one '
-                                          'optimizer step; use more ranks or a larger per-rank batch)')
             stepper = D.DataParallelStep(model, self.optimizer, self.world)
             self._comm = stepper.comm
+            # replica equality must not rest on every rank having drawn the same initial values from the same seed
+            D.broadcast_module(model, stepper.comm)
+            # contrastive models validate on the GLOBAL batch (comparable with a single-GPU run at the same global batch);
+            # anything else (classifier heads) validates per rank and the epoch means are averaged over the ranks (log())
+            self.dp_global_validation = hasattr(model, 'loss') and hasattr(model, 'encode')
+        every = self._val_interval(train_loader)
         for epoch in range(self.max_epochs):
             self.current_epoch = epoch
             if hasattr(getattr(train_loader, 'sampler', None), 'set_epoch'):
@@ -172,14 +228,31 @@ class Trainer:
             model.train()
             self.optimizer.zero_grad()
             pending = 0                                    # micro-batches accumulated since the last optimizer step
+            n_batches = None
+            if stepper is not None and self.accumulate > 1:
+                # the data-parallel step must know which micro-batch closes a window BEFORE it runs it (the gradient
+                # buckets cross the links during that backward): Lightning closes a short window on the epoch's last batch
+                n_batches = len(train_loader)
+                if self.limit_train_batches is not None:
+                    n_batches = min(n_batches, int(self.limit_train_batches))
+            validated_at_end = False
             for i, batch in enumerate(train_loader):
                 if self.limit_train_batches is not None and i >= self.limit_train_batches:
                     break
+                validated_at_end = False
                 if stepper is not None:
                     batch = self._to_device(batch)
                     batch['buckets'] = 1                  # the GLOBAL batch is one contrastive bucket (distributed.py)
-                    stepper.step(batch)
-                    self.global_step += 1
+                    if self.accumulate == 1:
+                        stepper.step(batch)
+                        self.global_step += 1
+                    else:
+                        window = min(self.accumulate, n_batches - (i - pending))      # (the epoch's last window may be short)
+                        stepper.step(batch, micro=pending, of=window)
+                        pending += 1
+                        if pending == window:
+                            pending = 0
+                            self.global_step += 1
                 else:
                     loss = model.training_step(self._to_device(batch), i)
                     ops.backward(loss / self.accumulate if self.accumulate > 1 else loss)
@@ -189,26 +262,24 @@ class Trainer:
                         self.optimizer.zero_grad()
                         pending = 0
                         self.global_step += 1
+                if (every is not None and valid_loader is not None and (i + 1) % every == 0
+                        and (epoch + 1) % self.check_val_every_n_epoch == 0):
+                    self._validate(model, valid_loader, stepper)
+                    validated_at_end = True
+                    if self.should_stop and epoch + 1 >= self.min_epochs:
+                        break
                 if 0 < self.max_steps <= self.global_step:
                     self.should_stop = True
                     break
-            if pending:
+            if pending and stepper is None:
                 # Lightning steps on the last batch of an epoch even when the accumulation window is not full
                 self.optimizer.step()
                 self.optimizer.zero_grad()
                 self.global_step += 1
             model.on_train_epoch_end()
-            if valid_loader is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:
-                model.eval()
-                with torch.no_grad():
-                    for i, batch in enumerate(valid_loader):
-                        if self.limit_val_batches is not None and i >= self.limit_val_batches:
-                            break
-                        model.validation_step(self._to_device(batch, training=False), i)
-                model.on_validation_epoch_end()
-                for cb in self.callbacks:
-                    if self.is_global_zero or not isinstance(cb, ModelCheckpoint):     # checkpoints: rank 0 only
-                        cb.on_validation_end(self, model, self.callback_metrics)
+            if (valid_loader is not None and (epoch + 1) % self.check_val_every_n_epoch == 0 and every is None
+                    and not validated_at_end):
+                self._validate(model, valid_loader, stepper)
             if self.should_stop and epoch + 1 >= self.min_epochs:
                 break
         return model

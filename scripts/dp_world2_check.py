@@ -3,7 +3,10 @@ the host) against a single-process reference of the same semantics -- per-rank B
 the GLOBAL batch, summed gradients.  Each mode writes its post-training parameters to <outdir>/<mode>.pt.
 
     RANK=r WORLD_SIZE=2 MPR_DIST_BACKEND=gloo python scripts/dp_world2_check.py rank <outdir> [method]
-    python scripts/dp_world2_check.py ref <outdir> [method] [steps]
+    python scripts/dp_world2_check.py ref <outdir> [method] [steps] [accumulate] [precision]
+
+accumulate > 1: every optimizer step is a window of that many micro-batches (Lightning's accumulate_grad_batches: each
+micro-batch's loss / accumulate); precision 32: the conv stacks' fp32 parity mode (no atomics: the comparison is tight).
 """
 import os, sys, yaml, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,6 +23,10 @@ card['profile_encoder_args']['dropout'] = 0.0
 card['coordination_args'] = {'method': method}
 B, T, WORLD = 8, card['target_size'], 2
 STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+OF = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+if len(sys.argv) > 6 and sys.argv[6] != '-':
+    from multimodal_plankton_recognition_amd import layers_f32
+    layers_f32.set_conv_precision(sys.argv[6])
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
 torch.manual_seed(0)
@@ -41,19 +48,22 @@ if mode == 'rank':
     D.init(dev, backend='gloo')
     stepper = D.DataParallelStep(model, opt, WORLD)
     for s in range(STEPS):
-        losses.append(float(stepper.step(shard(s, rank)).detach()))
+        for micro in range(OF):
+            losses.append(float(stepper.step(shard(s * OF + micro, rank), micro=micro, of=OF).detach()))
+    assert stepper.verified == [True] * min(STEPS, 2), stepper.verified
     D.barrier()
     D.shutdown()
     tag = f'rank{rank}'
 else:
     for s in range(STEPS):
         opt.zero_grad()
-        embs = [model.encode(**shard(s, r)) for r in range(WORLD)]          # per-rank BatchNorm statistics
-        loss = model.loss(image_emb=torch.cat([e['image_emb'] for e in embs]),
-                          profile_emb=torch.cat([e['profile_emb'] for e in embs]), buckets=1)
-        loss.backward()
+        for micro in range(OF):
+            embs = [model.encode(**shard(s * OF + micro, r)) for r in range(WORLD)]          # per-rank BatchNorm statistics
+            loss = model.loss(image_emb=torch.cat([e['image_emb'] for e in embs]),
+                              profile_emb=torch.cat([e['profile_emb'] for e in embs]), buckets=1)
+            (loss / OF if OF > 1 else loss).backward()
+            losses.append(float(loss.detach()))
         opt.step()
-        losses.append(float(loss.detach()))
     tag = 'ref'
 torch.cuda.synchronize()
 sd = {k: v.detach().float().cpu() for k, v in model.named_parameters()}

@@ -81,6 +81,14 @@ model = MultiModel(
     coordination_args=card_dict['coordination_args'],
     optim_args=card_dict['optim_args'],
 )
+if world > 1:
+    # the replicas share their parameters (same seed above, and Trainer.fit broadcasts rank 0's before the first step), NOT
+    # their randomness: loader workers, augmentation, crops / flips and dropout draw from per-rank streams from here on
+    import random
+    import numpy as np
+    torch.manual_seed(1 + rank)
+    random.seed(1 + rank)
+    np.random.seed(1 + rank)
 multi_collate = make_multi_collate(model, card_dict['buckets'])
 batch_transform = None
 if args.gpu_augment and not args.synthetic:

@@ -36,6 +36,11 @@ class _RecordingComm:
         self.calls.append((x.numel(), torch.cuda.current_stream().cuda_stream, self.phase))
         return _Work()
 
+    def sum_grads(self, x, async_op=False):
+        if async_op:
+            return [self.all_reduce_sum_async(x)]
+        return self.all_reduce_sum(x)
+
 
 def test_buckets_launch_from_backward_on_the_right_streams():
     import bench
@@ -80,3 +85,30 @@ def test_buckets_launch_from_backward_on_the_right_streams():
     # same parameters as the plain step
     for (n, a), (_, b) in zip(ref.named_parameters(), model.named_parameters()):
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-5), n
+
+
+def test_late_gradient_report_for_a_sent_bucket_raises():
+    """a parameter that reports a gradient AFTER its bucket went to the all-reduce (a shared / tied weight, a
+    module called twice) must fail loudly -- ranks would otherwise apply different gradients."""
+    import bench
+    from multimodal_plankton_recognition_amd import distributed as D, ops
+    from multimodal_plankton_recognition_amd.model import MultiModel
+    card = yaml.safe_load(open(bench.CARD))
+    torch.manual_seed(0)
+    model = MultiModel(card['dim_embedding'], card['image_encoder_args'], card['profile_encoder_args'],
+                       card['coordination_args'], card['optim_args']).to(DEV).train()
+    opt = model.configure_optimizers()
+    stepper = D.DataParallelStep(model, opt, 1, comm=_RecordingComm())
+    bk = stepper.buckets
+    bk.begin()
+    try:
+        p = next(iter(model.image_encoder.backbone.layer4.parameters()))
+        k = bk.owner[id(p)]
+        ops.grad_target(p)                      # first report: counted
+        assert id(p) in bk.count[k]
+        bk.sent[k] = True                       # ... the bucket has gone out
+        with pytest.raises(RuntimeError, match='already been sent'):
+            ops.grad_target(p)
+    finally:
+        bk.active = False
+        bk.close()

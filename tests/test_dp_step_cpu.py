@@ -103,3 +103,87 @@ def test_dp_step_rejects_buckets_and_rank_loss():
     m.loss = RankLoss(margin=0.25)
     with pytest.raises(NotImplementedError):
         D.DataParallelStep(m, torch.optim.SGD(m.parameters(), lr=0.1), 1, comm=object(), math=TorchMath())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 3: gradient accumulation under DP (the reference's own card sets accumulate_grad_batches: 4,
+# model_cards/example_multi.yaml:36-42), the reduce-scatter + all-gather form of the gradient sum, the GLOBAL-batch
+# validation loss, and the replica check of the first steps.
+def _worker_acc(rank, world, port, b, method, windows, of, collective, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from multimodal_plankton_recognition_amd import distributed as D
+    torch.set_num_threads(1)
+    D.init(backend='gloo')
+    model = _Double(method)
+    if rank == 1:                                   # replicas that did NOT start equal: the broadcast must repair it
+        with torch.no_grad():
+            model.image_encoder[0].weight.add_(0.5)
+    with pytest.raises(ValueError):
+        D.Comm(collective='ring')
+    comm = D.Comm(collective=collective)
+    D.broadcast_module(model, comm)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3, nesterov=True)
+    stepper = D.DataParallelStep(model, opt, world, comm=comm, math=TorchMath())
+    losses, s = [], 0
+    for _ in range(windows):
+        for micro in range(of):
+            img, prof = _data(world, b, s)
+            sl = slice(rank * b, (rank + 1) * b)
+            losses.append(float(stepper.step({'image': img[sl], 'profile': prof[sl], 'buckets': 1}, micro=micro, of=of)))
+            s += 1
+    img, prof = _data(world, b, 999)
+    sl = slice(rank * b, (rank + 1) * b)
+    model.valid_loss = []
+    with torch.no_grad():
+        val = float(stepper.validation_step({'image': img[sl], 'profile': prof[sl], 'buckets': 1}))
+    ok_before = list(stepper.verified)
+    # a replica that drifts (what a gradient written after its bucket was reduced would cause) is detected and repaired
+    if rank == 1:
+        with torch.no_grad():
+            model.profile_encoder[0].bias.add_(1e-3)
+    detected = not stepper.verify_replicas()
+    resynced = stepper.verify_replicas()
+    out[rank] = (losses, {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}, val, ok_before, detected,
+                 resynced)
+    D.barrier()
+    D.shutdown()
+
+
+@pytest.mark.parametrize('method,collective', [('clip', 'rs_ag'), ('siglipplus', 'all_reduce'), ('clipplus', 'rs_ag')])
+def test_dp_accumulation_validation_and_replica_check_world2(method, collective):
+    import warnings
+    world, b, windows, of = 2, 5, 2, 3
+    mgr = mp.Manager()
+    out = mgr.dict()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        mp.spawn(_worker_acc, args=(world, _free_port(), b, method, windows, of, collective, out), nprocs=world, join=True)
+    model = _Double(method)
+    core = model.loss if method in ('clip', 'siglip') else (model.loss.clip if method == 'clipplus' else model.loss.siglip)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3, nesterov=True)
+    ref_losses, s = [], 0
+    for _ in range(windows):
+        opt.zero_grad()
+        for _ in range(of):                          # Lightning: every micro-batch's loss / accumulate_grad_batches
+            img, prof = _data(world, b, s)
+            emb = model.encode(img, prof)
+            loss = _oracle_loss(method, core, emb['image_emb'], emb['profile_emb'])
+            (loss / of).backward()
+            ref_losses.append(float(loss))
+            s += 1
+        opt.step()
+    img, prof = _data(world, b, 999)
+    with torch.no_grad():
+        emb = model.encode(img, prof)
+        ref_val = float(_oracle_loss(method, core, emb['image_emb'], emb['profile_emb']))
+    ref_sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    for rank in range(world):
+        losses, sd, val, ok_before, detected, resynced = out[rank]
+        np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+        assert abs(val - ref_val) <= 2e-5 * abs(ref_val), (val, ref_val)       # the GLOBAL-batch loss, on every rank
+        assert ok_before == [True, True]              # the first two optimizer steps were checked on the "hardware"
+        assert detected and resynced
+        for k in ref_sd:
+            np.testing.assert_allclose(sd[k], ref_sd[k], rtol=2e-4, atol=2e-6, err_msg=f'rank {rank} {k}')
+    for k in ref_sd:                                  # after the re-synchronisation the replicas are bit-identical again
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k

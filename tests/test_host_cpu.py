@@ -139,3 +139,92 @@ def test_profile_resize_is_torchvisions_antialiased_bilinear(L, T):
                                                     align_corners=False)[0].numpy()
         assert np.abs(got - two_point).max() > 1e-2
     assert D.ProfileTransformTest(T)(prof).dtype == torch.float32
+
+
+def test_val_check_interval_follows_lightning():
+    """Trainer(val_check_interval=...) as lightning.Trainer reads it (the reference passes the card's value through:
+    scripts/train_multi.py:99-104): float = fraction of the training epoch, int = batches, None / 1.0 = end of epoch."""
+    loader = list(range(10))
+    assert Trainer(device='cpu')._val_interval(loader) is None
+    assert Trainer(device='cpu', val_check_interval=1.0)._val_interval(loader) is None
+    assert Trainer(device='cpu', val_check_interval=0.25)._val_interval(loader) == 2
+    assert Trainer(device='cpu', val_check_interval=0.01)._val_interval(loader) == 1
+    assert Trainer(device='cpu', val_check_interval=4)._val_interval(loader) == 4
+    assert Trainer(device='cpu', val_check_interval=0.5, limit_train_batches=4)._val_interval(loader) == 2
+    for bad in (0, -1, 1.5, 0.0, 11, 'often', True):
+        with pytest.raises(ValueError):
+            Trainer(device='cpu', val_check_interval=bad)._val_interval(loader)
+    with pytest.raises(ValueError):
+        Trainer(device='cpu', val_check_interval=0.5)._val_interval(iter(loader))
+
+
+def test_trainer_runs_validation_inside_the_epoch_and_keeps_accumulation_windows():
+    """Host logic of Trainer.fit on a CPU double: val_check_interval = 2 batches -> two validation runs in a 5-batch epoch
+    (none added at the epoch's end), accumulate_grad_batches = 2 -> optimizer steps after batches 2, 4 and the short last
+    window (Lightning steps on the epoch's last batch)."""
+    class Double(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(()))
+            self.events, self.current_epoch = [], 0
+
+        def configure_optimizers(self):
+            outer = self
+
+            class Opt(torch.optim.SGD):
+                def step(self, *a, **k):
+                    outer.events.append('step')
+                    return super().step(*a, **k)
+            return Opt(self.parameters(), lr=0.1)
+
+        def training_step(self, batch, i):
+            self.events.append(f'train{i}')
+            return (self.w - batch['x']) ** 2
+
+        def validation_step(self, batch, i):
+            self.events.append('val')
+
+        def on_train_epoch_end(self):
+            self.events.append('epoch_end')
+
+        def on_validation_epoch_end(self):
+            self.events.append('val_end')
+
+    m = Double()
+    import multimodal_plankton_recognition_amd.trainer as TR
+    old = TR.ops.backward
+    TR.ops.backward = lambda loss: loss.backward()          # (the product's cached-root backward needs a device)
+    try:
+        t = Trainer(device='cpu', max_epochs=1, accumulate_grad_batches=2, val_check_interval=2)
+        t.fit(m, [{'x': torch.tensor(float(i))} for i in range(5)], [{'x': torch.tensor(0.)}])
+    finally:
+        TR.ops.backward = old
+    assert m.events == ['train0', 'train1', 'step', 'val', 'val_end', 'train2', 'train3', 'step', 'val', 'val_end', 'train4',
+                        'step', 'epoch_end'], m.events
+    assert t.global_step == 3
+
+
+def test_backbone_with_a_live_block_chain_can_be_copied_and_pickled():
+    """BlockChain holds non-leaf tensors of the last forward; a deep copy / pickle of the module gets an empty
+    table shared by the copy's blocks."""
+    import copy
+    import pickle
+    from multimodal_plankton_recognition_amd.image_encoder import ResNetBackbone
+    m = ResNetBackbone((1, 1, 1, 1))
+    m._chain.notes[5] = (torch.zeros(2, requires_grad=True) * 2, None, None)
+    for m2 in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert m2._chain is not m._chain and not m2._chain.notes and not m2._chain.sums
+        assert all(b.chain is m2._chain for li in range(1, 5) for b in getattr(m2, f'layer{li}'))
+    assert 5 in m._chain.notes
+
+
+def test_conv_precision_switch():
+    from multimodal_plankton_recognition_amd import layers_f32
+    old = layers_f32._PRECISION[0]
+    try:
+        for name, want in (('32', True), ('32-true', True), (32, True), ('16-mixed', False), ('bf16-mixed', False),
+                           (None, False)):
+            layers_f32.set_conv_precision(name)
+            assert layers_f32.conv_f32() is want, name
+    finally:
+        layers_f32._PRECISION[0] = old
