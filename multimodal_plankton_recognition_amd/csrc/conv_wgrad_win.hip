@@ -8,13 +8,24 @@
 // DMA zero-fills).  The plain LDS-DMA kernel (conv_wgrad.hip) gathers a fresh [64 pixels][128 (tap, channel)] tile
 // per tap block -- 32 KB of operands per 2.1 MFLOP, which pins it to the CU's global->LDS fill rate.  Here a workgroup
 // owns ALL NINE taps of a (64*KH output channels) x (64 input channels) block: the 64 input channels of the pixels
-// live in a 256-row LDS ring that slides along the raster (64 new rows per 64-pixel chunk), the nine taps read it at
+// live in a 512-row LDS ring that slides along the raster (64 new rows per 64-pixel chunk), the nine taps read it at
 // shifted rows, and only dy streams beside it: 16-24 KB per 4.7-9.4 MFLOP chunk (295-393 FLOP/B).
 //
 // Workgroup: 3 (filter row r) x 2 (channel half) x KH (64-wide slab of output channels) waves; a wave accumulates
 // 2 x 3 MFMA tiles: [64 output channels] x [3 taps (r, 0..2) x 32 channels].  Both operands are pixel-major in
 // memory while the contraction runs over pixels, so fragments come from ds_read_b64_tr_b16 as in conv_wgrad.hip.
-// The pixel axis is split over workgroups; partial tiles are added into the [K][R][S][C] gradient with fp32 atomics.
+// The pixel axis is split over workgroups; partial tiles go to lent scratch + one reduction pass (or fp32 atomics).
+//
+// Round 3 (what bounded the loop, measured with the per-wave probe + SQ counters -- scripts/wgw_probe_resid.py,
+// scripts/prof_wgw_pmc.sh): not the LDS (SQ_LDS_BANK_CONFLICT 0, LDS array 26 % busy) and not the matrix pipe, but the SIMD's
+// VECTOR ISSUE -- ~50 VALU instructions of address arithmetic per k-step and wave beside six MFMAs, plus ~25 per DMA
+// instruction for the raster decode -- and the way a workgroup-wide barrier per chunk interacts with oldest-first wave
+// arbitration.  Now: fragment reads with immediate offsets off one base register per (fragment, chunk) (mirrored ring: no
+// wrap inside a chunk), reads interleaved with the MFMAs under counted lgkmcnt waits and pipelined across chunk boundaries,
+// raster decode from a per-geometry table, each wave's DMA in one early burst placed by wave age, s_setprio by k-step.
+// 3890 -> 2750 cycles per 64-pixel chunk (2304 = the MFMAs alone); launches at 160 workgroups 173-214 -> 142-164 us.
+// (Two six-wave workgroups per CU instead of one of twelve were tried first: the dispatcher never co-schedules them --
+//  a 6-wave group needs two waves on two of the SIMDs, and the resource check takes ceil(6/4) x 168 VGPRs on EVERY SIMD.)
 #include "common.h"
 
 struct WgwParams {
@@ -23,13 +34,16 @@ struct WgwParams {
   float* dw;           // [K][9*C]
   float* part;         // partial slices [nsplit][K][9*C] (plain stores + reduction pass) or NULL (atomics into dw)
   int H, W, C, K;
-  int Wp, img, Gtot, halo8;   // W+1, (H+1)*(W+1), B*img, (W+2) rounded up to 8
+  int Wp, img, Gtot, halo8, mir;   // W+1, (H+1)*(W+1), B*img, (W+2) rounded up to 8, mirrored ring rows (chunk + 2 halo8)
   int Ng, ncb, nkt, cps, total_chunks;
   unsigned x_bytes, dy_bytes;
   FastDiv div_img, div_wp;
   int dbg;   // timing experiments: bit 0 = skip the atomic epilogue
   unsigned long long* probe;   // timing experiments: 8 x uint64 shader-clock sums per workgroup (wave 0), or NULL
+  const uint32_t* rtab;        // raster table (runtime.cpp: mpr_raster_table): [margin + G] = pixel + 1, 0 = pad
+  unsigned rtab_bytes;
 };
+#define WGW_RASTER_MARGIN 256   // = MPR_RASTER_MARGIN of runtime.cpp
 
 template <int N>
 __device__ __forceinline__ void wgw_wait_vmcnt() {
@@ -47,29 +61,62 @@ __device__ __forceinline__ s16x4 wgw_read_tr(uint32_t lds_addr) {
   return v;
 }
 
+// Immediate-offset form of the transposing read: the k-step and the second half of a fragment are OFFSETS of one base
+// register per (fragment, chunk).  Round 3: with every address formed by VALU instructions (one v_add per read + the ring
+// wrap and swizzle of the x rows: ~50 per k-step and wave) the loop was bound by the SIMD's VECTOR ISSUE, not by the matrix
+// pipe or the LDS -- three waves x 50 x 4 cycles = 600 cycles of address arithmetic per k-step beside 576 of MFMA.
+template <int OFF>
+__device__ __forceinline__ s16x4 wgw_read_tr_o(uint32_t lds_addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+  return v;
+}
+// counted wait: LDS reads return in order, so "at most N outstanding" = everything older than the N youngest has landed;
+// the fragments that the following MFMA consumes ride through as in/out operands (ordering for the compiler)
+template <int N>
+__device__ __forceinline__ void wgw_wait_lgkm(s16x4& a, s16x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wgw_wait_lgkm(s16x4& a, s16x4& b, s16x4& c, s16x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int V>
+struct WgwInt { static constexpr int value = V; };
+
 // PS = 2 (64 output channels only): a chunk is 128 pixels and a second set of six waves works on its upper 64 -- twelve
-// waves per workgroup as at KH = 2, where six (1.5 per SIMD) left every wave's read -> wait -> MFMA chain exposed: the loop
-// took the same ~2700 cycles per 64 pixels with half the MFMA work.  The two halves' accumulators are summed through LDS
-// at the end.  The ring holds two chunks + both halos then (384 rows; 512 allocated).
-// PB = 2: every wave walks two 64-pixel blocks per chunk (8 k-steps between barriers instead of 4): the per-chunk fixed
-// costs -- barrier skew, DMA issue, the first fragments' LDS latency, ~1400 cycles -- are paid half as often.
-template <int KH, int PS = 1, int PB = 1>
+// waves per workgroup as at KH = 2, where six (1.5 per SIMD) left every wave's read -> wait -> MFMA chain exposed.  The two
+// halves' accumulators are summed through LDS at the end.
+//
+// LDS: [x ring: RING rows of 128 B][mirror: the ring's first CHUNK + 2 halo rows once more][3 dy stages].  The mirror makes a
+// chunk's window CONTIGUOUS (rows cbase .. cbase + CHUNK + 2 halo, no wrap), which is what lets the fragment reads use
+// immediate offsets; its rows are written by a second DMA instruction with the same source offsets (3 of 8 groups).
+//
+// Main loop, per wave and 16-pixel k-step: six MFMAs (2 tiles of output channels x 3 taps) and the ten transposing reads of
+// the NEXT k-step, two behind each MFMA, in the order their consumers run (A0 B0 A1 B1 B2) with counted lgkmcnt waits --
+// the pipeline runs on across chunk boundaries (the first fragments of chunk ci + 1 are read during the last k-step of
+// chunk ci: the barrier at the top of iteration ci has confirmed them).  The DMA instructions of chunk ci + 2 go out one per
+// k-step behind its first MFMA (an LDS-DMA instruction holds the wave's issue for 60-180 cycles).
+template <int KH, int PS = 1, int PRIO = 0, bool PROBE = false>
 __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const WgwParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(KH * PS <= 2, "twelve waves at most");
   constexpr int NW = 6 * KH * PS;
-  constexpr int CHUNK = 64 * PS * PB;          // pixels per chunk
+  constexpr int CHUNK = 64 * PS;               // pixels per chunk
+  constexpr int KSTEPS = 4;                    // 16-pixel k-steps per wave and chunk
   constexpr int RING = 512;                    // x ring rows (128 B each: 64 channels): 3 chunks + both halos (<= 512), power of two
+  constexpr int MIRMAX = CHUNK + 128;          // mirror rows allocated (p.mir = CHUNK + 2 halo8 of them are kept)
   constexpr int NST = 3;                       // dy stages: chunk ci + 2 is in flight while chunk ci is multiplied
-  constexpr int XBYTES = RING * 128;
+  constexpr int XBYTES = (RING + MIRMAX) * 128;
   constexpr int DROW = 128 * KH;               // dy stage row bytes (64*KH output channels)
   constexpr int DSTAGE = CHUNK * DROW;
   constexpr int D_INSTR = DSTAGE / 1024;       // 8*KH*PS DMA instructions per dy chunk
   constexpr int D_IT = (D_INSTR + NW - 1) / NW;
   constexpr int XI_IT = (CHUNK / 8 + 16 + NW - 1) / NW;    // initial window: up to CHUNK + 2*64 rows
   constexpr int XC_IT = (CHUNK / 8 + NW - 1) / NW;         // per chunk: CHUNK new rows
+  static_assert(XC_IT + D_IT <= KSTEPS, "one DMA piece per k-step");
   auto ring = [](int G) -> int { return G & (RING - 1); };
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [x ring 64 KB][dy stage 0][dy stage 1][dy stage 2]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [x ring + mirror][dy stage 0][dy stage 1][dy stage 2]
   unsigned char* const dyst = smem + XBYTES;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address of smem
 
@@ -101,19 +148,22 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
     pix = (b * p.H + hh) * p.W + ww;
     return hh < (uint32_t)p.H && ww < (uint32_t)p.W;
   };
-  // x rows [G8, G8+8) (G8 a multiple of 8) -> ring rows G8 & 255 ...; lane -> (row lane/8, physical chunk lane%8),
+  // x rows [G8, G8+8) (G8 a multiple of 8) -> ring rows ring(G8) ...; lane -> (row lane/8, physical chunk lane%8),
   // 64-B segment swizzle on the source side: logical chunk = ((pc >> 2) ^ ((row >> 1) & 1)) << 2 | (pc & 3)
+  // (bit 1 of the ring row is bit 1 of the row inside its group of eight: G8 and RING are multiples of 8)
   auto x_off = [&](int G8) -> uint32_t {
     const int G = G8 + (lane >> 3);
-    const int row = ring(G);
     const int pc = lane & 7;
-    const int lc = (((pc >> 2) ^ ((row >> 1) & 1)) << 2) | (pc & 3);
+    const int lc = (((pc >> 2) ^ ((lane >> 4) & 1)) << 2) | (pc & 3);
     uint32_t pix;
     return pixel_of(G, pix) ? pix * (uint32_t)(2 * p.C) + (uint32_t)((cb * 64 + lc * 8) * 2) : 0xFFFFFFF0u;
   };
   auto fire_x8 = [&](int G8, uint32_t v) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rs_x, (__attribute__((address_space(3))) void*)(smem + ring(G8) * 128), 16, v, 0, 0, 0);
+    const int rr = ring(G8);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + rr * 128), 16, v, 0, 0, 0);
+    if (rr < p.mir)      // (wave-uniform) the same rows once more behind the ring
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + (rr + RING) * 128), 16, v,
+                                               0, 0, 0);
   };
   auto issue_x8 = [&](int G8) { fire_x8(G8, x_off(G8)); };
   // dy rows of chunk ci -> stage ci % NST: instruction I covers 1024 / DROW rows
@@ -127,38 +177,67 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
     return pixel_of(ci * CHUNK + row, pix) ? pix * (uint32_t)(2 * p.K) + (uint32_t)((kt * 64 * KH + lc * 8) * 2)
                                         : 0xFFFFFFF0u;
   };
-  // The source offsets of a chunk's DMA (two fastdivs per lane and instruction) are computed ONE CHUNK AHEAD, underneath
-  // the MFMAs of the previous chunk; after the barrier only the buffer_load ... lds instructions themselves remain.
-  // (Computed right there they cost every wave ~900 cycles with the matrix pipe idle: all waves sit at the same point.)
-  uint32_t vx[XC_IT], vd[D_IT];
-  auto prep_chunk = [&](int ci) {       // chunk ci: its 64 leading-edge ring rows and its dy rows
-    const int lo = ci * CHUNK + p.halo8;                  // (first raster row behind the window of chunk ci - 1)
+  // Steady state.  The SIMD serves its oldest wave first, so between two barriers the first wave of a SIMD (wid < 4) runs
+  // ahead and then idles at the barrier while the youngest of the three finishes last, alone (round-3 per-wave probe: barrier
+  // waits 1300 / 450 / 70 cycles of 3200 per chunk).  An LDS-DMA instruction holds its wave's issue for 60-180 cycles, and what
+  // the LAST wave issues late in the chunk is fully exposed.  So every wave issues its whole share of chunk ci + 2's DMA in ONE
+  // burst early in iteration ci: the two younger waves of a SIMD behind their first MFMA of k-step 0 -- the oldest holds the
+  // matrix pipe then anyway --, the oldest behind its first MFMA of k-step 1, when the other two have theirs out and fill the
+  // pipe.  One wave-uniform branch per k-step 0 / 1 and wave.
+  // The raster position -> pixel map comes from the table (one dword per lane and piece, loaded a whole chunk before its use
+  // with a per-lane-constant voffset and a scalar soffset: no address VALU) instead of the two divisions of pixel_of:
+  // ~25 VALU instructions per piece, 400 of 3250 cycles per chunk.  t[J] holds piece J's table value, converted in place to
+  // the source offset at the top of the iteration that fires it, and is reloaded for the next chunk right behind the DMA.
+  constexpr int NP = XC_IT + D_IT;
+  // (K = 64 on twelve waves, where every byte of x and dy streams in from HBM once: every wave in k-step 0 -- 159 -> 139 us
+  //  per layer1 launch; dbg bit 5 flips the choice)
+  const int dma_ks = (wid < 4 && ((PS == 1) != ((p.dbg & 32) != 0))) ? 1 : 0;
+  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)p.rtab, 0, p.rtab_bytes, 0x00020000);
+  constexpr int DCH = DROW / 16;                               // 16-B chunks per dy row (8 or 16); 64 / DCH rows per instruction
+  const int lane_x4 = (lane >> 3) * 4, lane_d4 = (lane / DCH) * 4;
+  uint32_t xcol, dcol;                                         // column terms of the source offsets (- one row: the table holds pixel + 1)
+  {
+    const int pc = lane & 7;
+    const int lc = (((pc >> 2) ^ ((lane >> 4) & 1)) << 2) | (pc & 3);
+    xcol = (uint32_t)((cb * 64 + lc * 8) * 2 - 2 * p.C);
+    const int pd = lane % DCH, rin = lane / DCH;
+    const int key = DCH == 16 ? (rin & 3) : ((rin >> 1) & 1);
+    const int ld = (((pd >> 2) ^ key) << 2) | (pd & 3);
+    dcol = (uint32_t)((kt * 64 * KH + ld * 8) * 2 - 2 * p.K);
+  }
+  uint32_t t[NP];
 #pragma unroll
-    for (int j = 0; j < XC_IT; ++j) {
-      const int I = wid + j * NW;
-      vx[j] = ((CHUNK / 8) % NW == 0 || I < CHUNK / 8) ? x_off(lo + 8 * I) : 0xFFFFFFF0u;
-    }
-#pragma unroll
-    for (int j = 0; j < D_IT; ++j) {
-      const int I = wid + j * NW;
-      vd[j] = (D_INSTR % NW == 0 || I < D_INSTR) ? dy_off(ci, I) : 0xFFFFFFF0u;
+  for (int j = 0; j < NP; ++j) t[j] = 0;
+  // piece J of chunk ci (J < XC_IT: a group of eight x rows; else a kilobyte of dy rows): fire its DMA from the offsets in t[J]
+  auto fire_piece = [&](auto J_, int ci) {
+    constexpr int J = decltype(J_)::value;
+    if constexpr (J < XC_IT) {
+      const int I = wid + J * NW;
+      if ((CHUNK / 8) % NW == 0 || I < CHUNK / 8) fire_x8(ci * CHUNK + p.halo8 + 8 * I, t[J]);
+    } else if constexpr (J < NP) {
+      const int I = wid + (J - XC_IT) * NW;
+      if (D_INSTR % NW == 0 || I < D_INSTR)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rs_d, (__attribute__((address_space(3))) void*)(dyst + (ci % NST) * DSTAGE + I * 1024), 16, t[J], 0, 0, 0);
     }
   };
-  auto fire_chunk = [&](int ci) {
-    const int lo = ci * CHUNK + p.halo8;
-    unsigned char* st = dyst + (ci % NST) * DSTAGE;
-#pragma unroll
-    for (int j = 0; j < XC_IT; ++j) {
-      const int I = wid + j * NW;
-      if ((CHUNK / 8) % NW == 0 || I < CHUNK / 8) fire_x8(lo + 8 * I, vx[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < D_IT; ++j) {
-      const int I = wid + j * NW;
+  // ... and load its table value for chunk ci
+  auto load_piece = [&](auto J_, int ci) {
+    constexpr int J = decltype(J_)::value;
+    if constexpr (J < XC_IT) {
+      const int I = wid + J * NW;
+      if ((CHUNK / 8) % NW == 0 || I < CHUNK / 8)
+        t[J] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_x4, (ci * CHUNK + p.halo8 + 8 * I + WGW_RASTER_MARGIN) * 4, 0);
+    } else if constexpr (J < NP) {
+      const int I = wid + (J - XC_IT) * NW;
       if (D_INSTR % NW == 0 || I < D_INSTR)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(st + I * 1024), 16, vd[j],
-                                                 0, 0, 0);
+        t[J] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_d4, (ci * CHUNK + I * (64 / DCH) + WGW_RASTER_MARGIN) * 4, 0);
     }
+  };
+  auto convert_pieces = [&]() {
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+      t[j] = t[j] ? __umul24(t[j], (uint32_t)(2 * (j < XC_IT ? p.C : p.K))) + (j < XC_IT ? xcol : dcol) : 0xFFFFFFF0u;
   };
 
   f32x16 acc[2][3];     // [m-tile of 32 output channels][tap s]
@@ -179,10 +258,28 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   for (int i = 0; i < 2; ++i) {
     const int seg = wk * 2 + i;                                // 64-B segment = 32 output channels
     const int key = KH == 2 ? (lq & 3) : ((lq >> 1) & 1);
-    a_rd[i] = (wp * 64 * PB + rowl) * DROW + ((seg ^ key) << 6) + inseg;
+    a_rd[i] = lds0 + XBYTES + (wp * 64 + rowl) * DROW + ((seg ^ key) << 6) + inseg;
   }
+  // x fragment rows relative to the chunk's lowest window row (raster position ci * CHUNK - halo8), per tap column s
+  int rowoff[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) rowoff[s] = wp * 64 + rowl + (wr - 1) * p.Wp + (s - 1) + p.halo8;
+  // fragment base addresses of a chunk: k-step and fragment half are immediate offsets of these
+  uint32_t abase[2], bbase[3];
+  auto set_bases = [&](int ci) {
+    const int cbase = ring(ci * CHUNK - p.halo8);              // (scalar) ring row of the window's first row; no wrap behind it
+    const uint32_t ds = (uint32_t)((ci % NST) * DSTAGE);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = a_rd[i] + ds;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int r = cbase + rowoff[s];
+      bbase[s] = lds0 + r * 128 + ((wh ^ ((r >> 1) & 1)) << 6) + inseg;      // (r + 16 ks + 4) >> 1 has the parity of r >> 1
+    }
+  };
 
-  // ---- prologue: window of the first chunk + its dy
+  // ---- prologue: window of the first chunk + its dy, all of chunk c0 + 1 (every wave takes part, offsets by division),
+  //      and the DMA waves' table values of chunk c0 + 2 (fired in the first iteration)
   {
     const int lo = c0 * CHUNK - p.halo8, hi = c0 * CHUNK + CHUNK + p.halo8;
 #pragma unroll
@@ -190,59 +287,90 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
       const int G8 = lo + 8 * (wid + j * NW);
       if (G8 < hi) issue_x8(G8);
     }
-    prep_chunk(c0);          // (only its dy half is used: the window above already holds chunk c0's rows)
-    {
-      unsigned char* st = dyst + (c0 % NST) * DSTAGE;
+    auto issue_dy = [&](int ci) {
 #pragma unroll
       for (int j = 0; j < D_IT; ++j) {
         const int I = wid + j * NW;
         if (D_INSTR % NW == 0 || I < D_INSTR)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (__attribute__((address_space(3))) void*)(st + I * 1024), 16, vd[j],
-                                                   0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              rs_d, (__attribute__((address_space(3))) void*)(dyst + (ci % NST) * DSTAGE + I * 1024), 16, dy_off(ci, I), 0, 0, 0);
       }
-    }
-    // two chunks of look-ahead: chunk c0 + 1 goes out here, the offsets of c0 + 2 are prepared for the first iteration
+    };
+    issue_dy(c0);
     if (c0 + 1 < c1) {
-      prep_chunk(c0 + 1);
-      fire_chunk(c0 + 1);
+#pragma unroll
+      for (int j = 0; j < XC_IT; ++j) {
+        const int I = wid + j * NW;
+        if ((CHUNK / 8) % NW == 0 || I < CHUNK / 8) issue_x8((c0 + 1) * CHUNK + p.halo8 + 8 * I);
+      }
+      issue_dy(c0 + 1);
     }
-    if (c0 + 2 < c1) prep_chunk(c0 + 2);
+    if (c0 + 2 < c1) {      // (table values: converted at the top of the first iteration)
+      load_piece(WgwInt<0>{}, c0 + 2); load_piece(WgwInt<1>{}, c0 + 2); load_piece(WgwInt<2>{}, c0 + 2); load_piece(WgwInt<3>{}, c0 + 2);
+    }
     wgw_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
   unsigned long long pr_wait = 0, pr_bar = 0, pr_comp = 0, pr_iss = 0;
-#define WGW_NOW() (p.probe ? __builtin_readcyclecounter() : 0ull)
+#define WGW_NOW() (PROBE ? __builtin_readcyclecounter() : 0ull)
   const unsigned long long pr_t0 = WGW_NOW();
+  const unsigned long long pr_w0 = PROBE ? (wall_clock64() & 0xFFFFFFFFull) : 0ull;
+
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x4 ra[2][2][2], rb[2][3][2];      // [buffer][tile][half]: the fragments of k-step ks live in buffer ks & 1
+#define WGW_FRAG(v) __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector((v)[0], (v)[1], 0, 1, 2, 3, 4, 5, 6, 7))
+#define WGW_RA(buf, i, KN) do { ra[buf][i][0] = wgw_read_tr_o<(KN) * 16 * DROW>(abase[i]); ra[buf][i][1] = wgw_read_tr_o<(KN) * 16 * DROW + 4 * DROW>(abase[i]); } while (0)
+#define WGW_RB(buf, s, KN) do { rb[buf][s][0] = wgw_read_tr_o<(KN) * 2048>(bbase[s]); rb[buf][s][1] = wgw_read_tr_o<(KN) * 2048 + 512>(bbase[s]); } while (0)
+#define WGW_MFMA(i, s) acc[i][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WGW_FRAG(ra[cur][i]), WGW_FRAG(rb[cur][s]), acc[i][s], 0, 0, 0)
+  // one k-step: the MFMAs of step KS (fragments in buffer KS & 1) with the reads of the next step behind them; `slot_a` runs
+  // behind the first MFMA (the wave's share of the next-but-one chunk's DMA, in k-step 0 or 1).  When KS is the chunk's last step the
+  // bases have been switched to the next chunk already.  Outstanding reads at the top: the ten of this step, in the order
+  // A0 B0 A1 B1 B2 (two each).
+  auto kstep = [&](auto KS_, auto&& slot_a) {
+    constexpr int KS = decltype(KS_)::value;
+    constexpr int cur = KS & 1, nxt = cur ^ 1, KN = (KS + 1) % KSTEPS;
+    // a wave that is behind outranks one that is ahead -- the SIMD otherwise serves its oldest wave first, which then idles at
+    // the barrier while the youngest finishes alone
+    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(3 - KS);
+    wgw_wait_lgkm<6>(ra[cur][0][0], ra[cur][0][1], rb[cur][0][0], rb[cur][0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    WGW_MFMA(0, 0);
+    WGW_RA(nxt, 0, KN);
+    slot_a();
+    __builtin_amdgcn_sched_barrier(0);
+    wgw_wait_lgkm<6>(ra[cur][1][0], ra[cur][1][1]);        // younger: B1 B2 A0'
+    __builtin_amdgcn_sched_barrier(0);
+    WGW_MFMA(1, 0);
+    WGW_RB(nxt, 0, KN);
+    __builtin_amdgcn_sched_barrier(0);
+    wgw_wait_lgkm<6>(rb[cur][1][0], rb[cur][1][1]);        // younger: B2 A0' B0'
+    __builtin_amdgcn_sched_barrier(0);
+    WGW_MFMA(0, 1);
+    WGW_RA(nxt, 1, KN);
+    __builtin_amdgcn_sched_barrier(0);
+    WGW_MFMA(1, 1);
+    WGW_RB(nxt, 1, KN);
+    __builtin_amdgcn_sched_barrier(0);
+    wgw_wait_lgkm<8>(rb[cur][2][0], rb[cur][2][1]);        // younger: A0' B0' A1' B1'
+    __builtin_amdgcn_sched_barrier(0);
+    WGW_MFMA(0, 2);
+    WGW_RB(nxt, 2, KN);
+    __builtin_amdgcn_sched_barrier(0);
+    WGW_MFMA(1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // first fragments of the first chunk
+  set_bases(c0);
+  WGW_RA(0, 0, 0); WGW_RB(0, 0, 0); WGW_RA(0, 1, 0); WGW_RB(0, 1, 0); WGW_RB(0, 2, 0);
   // Loop invariant at the top of iteration ci: chunk ci's operands are in LDS for EVERY wave (confirmed by the previous
-  // barrier), chunk ci + 1's are in flight (issued one iteration ago).  So the first fragment reads of chunk ci go out
-  // BEFORE this iteration's wait + barrier -- which only confirm chunk ci + 1 and release the stage / ring rows that chunk
-  // ci + 2 overwrites (last read in iteration ci - 1) -- and the matrix pipe is not drained at every chunk boundary: with a
-  // two-stage ring the barrier sat between the DMA wait and the first LDS read, ~1100 idle cycles per 2300-cycle chunk.
+  // barrier), chunk ci + 1's are in flight (issued one iteration ago); the first fragment reads of chunk ci are out.  The
+  // wait + barrier confirm chunk ci + 1 and release the stage / ring rows that chunk ci + 2 overwrites (last read in
+  // iteration ci - 1: a wave that has passed its last k-step's waits has every one of that chunk's reads back).
+  // (The table values are converted UNCONDITIONALLY at the top, so that the compiler knows every t[J] a DMA instruction takes
+  //  its offsets from is ready; with the conversion under a condition it guarded EACH DMA instruction with s_waitcnt vmcnt(0),
+  //  i.e. waited for the previous one to land.)
   for (int ci = c0; ci < c1; ++ci) {
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const uint32_t da = lds0 + XBYTES + (ci % NST) * DSTAGE;
-    // software-pipelined k-steps: wait for the fragments of step ks, put the reads of step ks+1 in flight, then the
-    // six MFMAs of step ks
-    s16x4 ra[2][2][2], rb[2][3][2];      // [buffer][tile][half]
-    auto issue_reads = [&](int buf, int ks) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const uint32_t pa = da + a_rd[i] + ks * 16 * DROW;
-        ra[buf][i][0] = wgw_read_tr(pa);
-        ra[buf][i][1] = wgw_read_tr(pa + 4 * DROW);
-      }
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int d = (wr - 1) * p.Wp + (s - 1);
-        const int r0 = ring(ci * CHUNK + wp * 64 * PB + ks * 16 + rowl + d);
-        const int r1 = (r0 + 4) & (RING - 1);
-        const int lowb = ((wh ^ ((r0 >> 1) & 1)) << 6) + inseg;       // (r0 + 4) >> 1 has the parity of r0 >> 1
-        rb[buf][s][0] = wgw_read_tr(lds0 + r0 * 128 + lowb);
-        rb[buf][s][1] = wgw_read_tr(lds0 + r1 * 128 + lowb);
-      }
-    };
-    issue_reads(0, 0);
     const unsigned long long q0 = WGW_NOW();
     wgw_wait_vmcnt<0>();
     const unsigned long long q1 = WGW_NOW();
@@ -251,46 +379,45 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
     const unsigned long long q2 = WGW_NOW();
     pr_wait += q1 - q0;
     pr_bar += q2 - q1;
-    // chunk ci + 2: its new ring rows at the leading edge + its dy (stage and rows were last read in iteration ci - 1)
-    if (ci + 2 < c1) fire_chunk(ci + 2);
-    const unsigned long long q3 = WGW_NOW();
-    pr_iss += q3 - q2;
+    // chunk ci + 2's source offsets from the table values loaded one iteration ago (the wait above covers them; chunk
+    // c0 + 2's were loaded in the prologue).  Slot J of the k-steps: fire piece J of chunk ci + 2, reload t[J] for chunk ci + 3.
+    const bool more2 = ci + 2 < c1 && !(p.dbg & 8);      // (dbg bit 3: timing experiment, no DMA issue in the loop)
+    const bool more3 = ci + 3 < c1 && !(p.dbg & 4);      // (dbg bit 2: no table loads)
+    auto dma_burst = [&]() {
+      if (more2) { fire_piece(WgwInt<0>{}, ci + 2); fire_piece(WgwInt<1>{}, ci + 2); fire_piece(WgwInt<2>{}, ci + 2); fire_piece(WgwInt<3>{}, ci + 2); }
+      if (more3) { load_piece(WgwInt<0>{}, ci + 3); load_piece(WgwInt<1>{}, ci + 3); load_piece(WgwInt<2>{}, ci + 3); load_piece(WgwInt<3>{}, ci + 3); }
+    };
+    kstep(WgwInt<0>{}, [&]() {
+      // (behind the first MFMA; pinned by an empty asm that "uses" every offset: the optimizer otherwise sinks each conversion
+      //  into the conditional block of its DMA instruction, behind a counted vmcnt wait that by then also covers the DMA
+      //  instructions just issued)
+      convert_pieces();
 #pragma unroll
-    for (int ks = 0; ks < 4 * PB; ++ks) {
-      const int cur = ks & 1;
-      // (per-wave probe, scripts/wgw_probe_waves.py: the three waves of a SIMD are served oldest first -- 2196 / 2491 / 2818
-      //  cycles of "compute" per chunk, barrier waits 820 / 460 / 96 -- and the youngest runs its last k-steps alone at
-      //  LDS-latency pace: ~900 of the 3200 cycles per chunk.  Rotating s_setprio per k-step made it worse: 3700.)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(ra[cur][0][0]), "+v"(ra[cur][0][1]), "+v"(ra[cur][1][0]), "+v"(ra[cur][1][1]),
-                     "+v"(rb[cur][0][0]), "+v"(rb[cur][0][1]), "+v"(rb[cur][1][0]), "+v"(rb[cur][1][1]),
-                     "+v"(rb[cur][2][0]), "+v"(rb[cur][2][1])
-                   :
-                   : "memory");
-      if (ks < 4 * PB - 1) issue_reads(cur ^ 1, ks + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      bf16x8 af[2], bfr[3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        af[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(ra[cur][i][0], ra[cur][i][1], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-        bfr[s] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(rb[cur][s][0], rb[cur][s][1], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-          acc[i][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[s], acc[i][s], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks == 1 && ci + 3 < c1) prep_chunk(ci + 3);      // address arithmetic underneath the MFMAs just issued
-    }
-    pr_comp += WGW_NOW() - q3;
+      for (int j = 0; j < NP; ++j) asm volatile("" : "+v"(t[j]));
+      if (dma_ks == 0) dma_burst();
+    });
+    kstep(WgwInt<1>{}, [&]() { if (dma_ks == 1) dma_burst(); });
+    kstep(WgwInt<2>{}, [&]() {});
+    // the next chunk's bases (its first fragments are read during this chunk's last k-step; beyond the last chunk the
+    // reads are dummies that keep the wait counts uniform: any address inside the allocation is fine)
+    set_bases(ci + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    kstep(WgwInt<3>{}, [&]() {});
+    pr_comp += WGW_NOW() - q2;
   }
-  if (p.probe && (p.dbg & 2) && lane == 0) {      // per-wave probe: 16 x 8 uint64 per workgroup (mpr_conv_set_wgrad_window(1 | 2 << 8))
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the dummy reads of the last k-step
+#undef WGW_MFMA
+#undef WGW_RB
+#undef WGW_RA
+#undef WGW_FRAG
+  if (PROBE && p.probe && (p.dbg & 2) && lane == 0) {      // per-wave probe: 16 x 8 uint64 per workgroup (mpr_conv_set_wgrad_window(1 | 2 << 8))
     unsigned long long* o = p.probe + ((size_t)blockIdx.x * 16 + wid) * 8;
     o[0] = WGW_NOW() - pr_t0; o[1] = pr_wait; o[2] = pr_bar; o[3] = pr_iss; o[4] = pr_comp; o[5] = (unsigned long long)(c1 - c0);
+    // where and when: HW_ID (wave slot 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13) | XCC_ID << 32; start / end on the 100 MHz clock
+    o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    o[7] = pr_w0 | (wall_clock64() << 32);
   } else
-  if (p.probe && tid == 0) {
+  if (PROBE && p.probe && tid == 0) {
     unsigned long long* o = p.probe + (size_t)blockIdx.x * 8;
     o[0] = WGW_NOW() - pr_t0; o[1] = pr_wait; o[2] = pr_bar; o[3] = pr_iss; o[4] = pr_comp; o[5] = (unsigned long long)(c1 - c0);
   }
@@ -363,6 +490,7 @@ __global__ __launch_bounds__(256) void wgw_reduce_kernel(const float4* __restric
   }
 }
 
+extern "C" const uint32_t* mpr_raster_table(int B, int H, int W, long long* entries);   // runtime.cpp
 static int g_wgw_on = 1;
 static float* g_wgw_scratch = nullptr;        // lent by the caller for the NEXT launch (mpr_conv_set_wgrad_scratch)
 static long long g_wgw_scratch_floats = 0;
@@ -393,7 +521,8 @@ int mpr_conv_debug_wgrad_probe(void* buf) {   // 8 x uint64 per workgroup of the
 bool mpr_wgw_eligible(long long Mpix, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
                       long long min_pix) {
   return g_wgw_on && R == 3 && S == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && C % 64 == 0 && K % 64 == 0 &&
-         W >= 2 && W <= 56 && H >= 2 && Mpix >= min_pix && (Mpix / (H * W)) * (long long)(H + 1) * (W + 1) < (1ll << 30);
+         W >= 2 && W <= 56 && H >= 2 && Mpix >= min_pix && Mpix < (1ll << 24) /* 24-bit multiply of the table path */ &&
+         (Mpix / (H * W)) * (long long)(H + 1) * (W + 1) < (1ll << 30);
 }
 
 // dw [K][3][3][C] += (zeroed by the caller unless accumulating) the weight gradient of x [B,H,W,C], dy [B,H,W,K]
@@ -413,12 +542,10 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   p.Wp = W + 1; p.img = (H + 1) * (W + 1); p.Gtot = B * p.img; p.halo8 = (W + 2 + 7) / 8 * 8;
   p.Ng = 9 * C; p.ncb = C / 64;
   const int KH = K % 128 == 0 ? 2 : 1;
-  const int PS = (KH == 1 && g_wgw_on != 2) ? 2 : 1;      // (mpr_conv_set_wgrad_window(2): round-1 forms, comparisons)
-  // (two pixel blocks per chunk at K % 128 == 0: 170 -> 158 us on layer2's shape, 149 -> 155 on layer3's, 168 -> 170 on
-  //  layer4's -- the barrier is not what the loop loses; kept as mpr_conv_set_wgrad_window(3) for experiments)
-  const int PB = (KH == 2 && g_wgw_on == 3) ? 2 : 1;
+  const int PS = (KH == 1 && g_wgw_on != 2) ? 2 : 1;      // (mpr_conv_set_wgrad_window(2): the six-wave form at K = 64, comparisons)
   p.nkt = K / (64 * KH);
-  p.total_chunks = ceil_div(p.Gtot, 64 * PS * PB);
+  p.total_chunks = ceil_div(p.Gtot, 64 * PS);
+  p.mir = 64 * PS + 2 * p.halo8;
   const int tiles = p.ncb * p.nkt;
   int nsplit = (target_wgs > 0 ? target_wgs : g_wgw_target) / tiles;
   if (nsplit > ceil_div(p.total_chunks, 4)) nsplit = ceil_div(p.total_chunks, 4);
@@ -430,39 +557,38 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   p.div_img = make_fastdiv(p.img); p.div_wp = make_fastdiv(p.Wp);
   p.dbg = g_wgw_dbg;
   p.probe = g_wgw_probe;
+  long long rt_entries = 0;
+  p.rtab = mpr_raster_table(B, H, W, &rt_entries);
+  MPR_REQUIRE(p.rtab != nullptr, "conv_wgrad (window): raster table allocation failed");
+  p.rtab_bytes = (unsigned)(rt_entries * 4);
   // partial slices instead of atomics when the caller lent enough scratch for THIS launch (one-shot)
   p.part = (scratch && (long long)nsplit * K * p.Ng <= scratch_floats) ? scratch : nullptr;
   const dim3 grid(nsplit * tiles);
-  const size_t lds = (size_t)512 * 128 + 3 * (size_t)(64 * PS * PB) * 128 * KH;      // x ring + three dy stages
-  if (PB == 2) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    conv_wgrad_win_kernel<2, 1, 2><<<grid, 768, lds, st>>>(p);
-  } else if (PS == 2) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    conv_wgrad_win_kernel<1, 2><<<grid, 768, lds, st>>>(p);
-  } else if (KH == 2) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    conv_wgrad_win_kernel<2><<<grid, 768, lds, st>>>(p);
-  } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    conv_wgrad_win_kernel<1><<<grid, 384, lds, st>>>(p);
-  }
+  // x ring + its mirror + three dy stages: 136 KB (K % 128 == 0), 144 KB (K = 64 on twelve waves), 112 KB (six waves)
+  const size_t lds = (size_t)(512 + 64 * PS + 128) * 128 + 3 * (size_t)(64 * PS) * 128 * KH;
+#define MPR_WGW(KH_, PS_, PRIO_, PROBE_)                                                                               \
+  do {                                                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<KH_, PS_, PRIO_, PROBE_>,                                 \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                     \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    conv_wgrad_win_kernel<KH_, PS_, PRIO_, PROBE_><<<grid, 384 * KH_ * PS_, lds, st>>>(p);                             \
+  } while (0)
+#define MPR_WGW2(KH_, PS_)                                                                                             \
+  do {                                                                                                                 \
+    if (p.probe) { if (prio) MPR_WGW(KH_, PS_, 1, true); else MPR_WGW(KH_, PS_, 0, true); }                            \
+    else { if (prio) MPR_WGW(KH_, PS_, 1, false); else MPR_WGW(KH_, PS_, 0, false); }                                  \
+  } while (0)
+  // s_setprio by k-step (a wave that is behind outranks one that is ahead): 3125 -> 2750 cycles per chunk at K % 128 == 0,
+  // 139 -> 134 us per layer1 launch; dbg bit 4 switches it off (comparisons)
+  const bool prio = !(p.dbg & 16);
+  if (PS == 2) MPR_WGW2(1, 2);
+  else if (KH == 2) MPR_WGW2(2, 1);
+  else MPR_WGW2(1, 1);
+#undef MPR_WGW2
+#undef MPR_WGW
   MPR_LAUNCH_CHECK("conv_wgrad_win_kernel");
   if (p.part) {
     const int n4 = K * p.Ng / 4;

@@ -6,6 +6,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -18,6 +21,46 @@ struct ProfRec {
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
+
+// ---- padded-raster lookup tables of the shifted-window kernels ------------------------------------
+// The window kernels (conv_win.hip, conv_wgrad_win.hip) number pixels in a padded raster, G = (b (H+1) + h)(W+1) + w.
+// Turning G back into a pixel index costs two divisions per lane -- ~25 VALU instructions per DMA instruction, which in the
+// weight-gradient loop added up to 400 of 3250 cycles per chunk (round-3 probe).  The map depends on (B, H, W) only, so it
+// is tabulated ONCE per geometry: tab[G + MPR_RASTER_MARGIN] = pixel index + 1, or 0 for a pad position / outside the
+// raster.  Built on the host and copied synchronously (a few hundred KB .. 6.6 MB), kept for the life of the process.
+#define MPR_RASTER_MARGIN 256
+#define MPR_RASTER_TAIL 1024
+static std::mutex g_raster_mu;
+static std::map<std::tuple<int, int, int, int>, std::pair<uint32_t*, long long>> g_raster;
+
+extern "C" const uint32_t* mpr_raster_table(int B, int H, int W, long long* entries) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_raster_mu);
+  const auto key = std::make_tuple(dev, B, H, W);
+  auto it = g_raster.find(key);
+  if (it == g_raster.end()) {
+    const long long img = (long long)(H + 1) * (W + 1), Gtot = (long long)B * img;
+    const long long n = MPR_RASTER_MARGIN + Gtot + MPR_RASTER_TAIL;
+    std::vector<uint32_t> host((size_t)n, 0u);
+    uint32_t* q = host.data() + MPR_RASTER_MARGIN;
+    for (int b = 0; b < B; ++b)
+      for (int h = 0; h < H; ++h) {
+        uint32_t* row = q + ((long long)b * (H + 1) + h) * (W + 1);
+        const uint32_t pix1 = (uint32_t)(((long long)b * H + h) * W) + 1u;
+        for (int w = 0; w < W; ++w) row[w] = pix1 + (uint32_t)w;
+      }
+    uint32_t* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)n * 4) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, host.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      hipFree(d);
+      return nullptr;
+    }
+    it = g_raster.emplace(key, std::make_pair(d, n)).first;
+  }
+  if (entries) *entries = it->second.second;
+  return it->second.first;
+}
 
 extern "C" {
 

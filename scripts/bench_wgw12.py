@@ -21,7 +21,7 @@ for B, H, W, C in [(512, 56, 56, 64), (64, 56, 56, 64), (37, 19, 23, 64), (512, 
     ref = None
     if B * H * W <= 64 * 56 * 56:
         ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (K, C, 3, 3), dy.float().permute(0, 3, 1, 2), padding=1)
-    for tgt in (256, 512):
+    for tgt in (160, 256, 512):
         N.query('mpr_conv_set_wgrad_target_wgs', tgt)
         for name, mode in [('round 2', 1), ('round 1', 2)]:
             N.query('mpr_conv_set_wgrad_window', mode)
