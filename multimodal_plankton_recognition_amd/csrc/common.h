@@ -73,10 +73,13 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
-  uint16_t ua = __builtin_bit_cast(uint16_t, a), ub = __builtin_bit_cast(uint16_t, b);
-  return (uint32_t)ua | ((uint32_t)ub << 16);
+  // ONE v_cvt_pk_bf16_f32 (RNE, NaN-preserving).  Two scalar conversions + (ua | ub << 16) compile to two conversions, a shift
+  // and an SDWA or: four VALU instructions per pair in every epilogue of the library.
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);

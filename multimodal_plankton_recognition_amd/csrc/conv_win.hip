@@ -43,7 +43,10 @@ struct WinParams {
   const bf16_t* mask_y;        // [B,H,W,Nout] (mode 1)
   const bf16_t* bn_x;          // [B,H,W,Nout] BatchNorm input: xhat = (bn_x - mean) * invstd
   const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;   // [Nout]
+  const uint32_t* rtab;        // raster table (runtime.cpp: mpr_raster_table): [256 + G] = pixel + 1, 0 = pad (conv_win_l1_kernel)
+  unsigned rtab_bytes;
 };
+#define WIN_RASTER_MARGIN 256   // = MPR_RASTER_MARGIN of runtime.cpp
 
 __device__ __forceinline__ int win_swz(int row, int chunk) {   // byte offset in a [rows][128 B] image
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -786,6 +789,280 @@ __global__ __launch_bounds__(256, 2) void conv_win_persist_kernel(const WinParam
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 64 -> 64 channels (ResNet layer1) with the WHOLE FILTER IN REGISTERS (round 3).  The persistent kernel above streams the
+// filter through its 2-stage ring once per tile: 72 KB of weights beside a 47 KB window, 119 KB of LDS-DMA per 18.9 MFLOP
+// tile -- at the CU's ~30 B/clk fill rate that is 4 K cycles per tile, as long as the tile's 4.6 K cycles of MFMA work --
+// with a workgroup barrier per tap.  These convolutions are HBM-bound by their arithmetic (288 FLOP per byte of activation
+// moved: 65 us per launch at batch 512), so everything beside the activation stream has to go: here a wave owns
+// 128 pixels x 32 output channels, its B operand -- 9 taps x 4 k-steps x one 32 x 16 fragment -- is 144 VGPRs loaded once
+// per kernel, the loop over the nine taps has NO barrier and NO weight traffic, and one LDS fragment read feeds one MFMA
+// (1 KB per 32 cycles and SIMD: half the LDS rate).  Workgroup = 4 waves (2 pixel halves x 2 channel halves) on a
+// 256-position tile, persistent over tiles, two workgroups per CU (<= 256 VGPRs); per tile two barriers (window landed /
+// window free), the next window's DMA under the wave-private epilogue, raster decode from the table.
+template <int V>
+struct WinInt { static constexpr int value = V; };
+template <int I, int N, class F>
+__device__ __forceinline__ void win_unroll(F&& f) {      // f(WinInt<I>) ... f(WinInt<N-1>), indices as compile-time constants
+  if constexpr (I < N) {
+    f(WinInt<I>{});
+    win_unroll<I + 1, N>(f);
+  }
+}
+template <bool DGRAD, bool PROBE = false>
+__global__ __launch_bounds__(256, 2) void conv_win_l1_kernel(const WinParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = 4, BM = 256;
+  constexpr int WI_MAX = (BM + 2 * 58 + 7) / 8, WIW = (WI_MAX + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [window][4 waves x 2 KB staging][4 waves x 4 KB sums][8 KB: ninth tap]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int wrows8 = (p.wrows + 7) & ~7;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t stage_lds = lds0 + wrows8 * 128 + wid * 2048;
+  const int ntiles = (p.Gtot + BM - 1) / BM;
+  const int frow = lane & 31, fh = lane >> 5;
+
+  // ---- the filter: breg[tap][ks] = rows wn*32 + frow of the panel, channels tap*64 + ks*16 + fh*8 .. +7
+  //      (taps 0..7: 128 VGPRs; the ninth tap's four fragments live in LDS -- 8 KB per workgroup, one extra ds_read_b128 per
+  //       four MFMAs in 4 of the 36 steps: with all 144 in registers the compiler spills table values around the window DMA)
+  bf16x8 breg[8][4];
+  unsigned char* const wtap8 = smem + wrows8 * 128 + NW * 2048 + NW * 4096;      // [wn][ks][64 lanes x 16 B]
+  unsigned char* const sink = wtap8 + 8192;                                       // 1 KB: DMA instructions past the window
+  {
+    const bf16_t* wrow = p.wpk + (size_t)(wn * 32 + frow) * p.Kgpad + fh * 8;
+#pragma unroll
+    for (int tap = 0; tap < 8; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) breg[tap][ks] = *reinterpret_cast<const bf16x8*>(wrow + tap * 64 + ks * 16);
+    if (wm == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        *reinterpret_cast<bf16x8*>(wtap8 + (wn * 4 + ks) * 1024 + lane * 16) = *reinterpret_cast<const bf16x8*>(wrow + 8 * 64 + ks * 16);
+    }
+    __syncthreads();
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)p.rtab, 0, p.rtab_bytes, 0x00020000);
+
+  // ---- window DMA: instruction I = wid + 4k covers window rows 8I..8I+7 (lane -> row lane/8, physical chunk lane%8, bank
+  //      swizzle on the source side: logical chunk = physical ^ ((row >> 1) & 7), constant per lane: 4I & 7 = 4 (wid & 1))
+  const int lane_r4 = (lane >> 3) * 4;
+  const uint32_t wcol = (uint32_t)((((lane & 7) ^ ((4 * wid + (lane >> 4)) & 7)) * 16) - 2 * p.C);      // (- one pixel: the table holds pixel + 1)
+  uint32_t wt[WIW];      // table values, then source offsets, of this wave's window instructions
+  auto load_window_tab = [&](int G0) {
+#pragma unroll
+    for (int k = 0; k < WIW; ++k)
+      wt[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_r4, (G0 - p.halo + 8 * (wid + k * NW) + WIN_RASTER_MARGIN) * 4, 0);
+  };
+  // All table values are converted BEFORE the first DMA instruction goes out, and pinned there by an empty asm: converted one by
+  // one in front of their DMA instructions (where the optimizer sinks them otherwise) the last conversions wait with
+  // s_waitcnt vmcnt(0) -- the counter is in order -- for every DMA instruction already issued to LAND: 4.7 K cycles per tile.
+  auto issue_window = [&]() {
+#pragma unroll
+    for (int k = 0; k < WIW; ++k) wt[k] = wt[k] ? __umul24(wt[k], (uint32_t)(2 * p.C)) + wcol : 0xFFFFFFF0u;
+#pragma unroll
+    for (int k = 0; k < WIW; ++k) asm volatile("" : "+v"(wt[k]));
+    // (no branches: an instruction past the window's last row group reads nothing -- out-of-range offset -- into a 1 KB sink
+    //  behind everything else; as wave-uniform branches the twelve instructions cost 24 taken branches per tile and wave)
+#pragma unroll
+    for (int k = 0; k < WIW; ++k) {
+      const int I = wid + k * NW;
+      const bool in = 8 * I < wrows8;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(in ? smem + I * 1024 : sink), 16,
+                                               in ? wt[k] : 0xFFFFFFF0u, 0, 0, 0);
+    }
+  };
+
+  // epilogue geometry: lane -> (row lane/4 + 16 it, 16-B chunk lane%4) of a 32 x 32 block; its 8 channels are fixed
+  const int erow = lane >> 2, ech = lane & 3;
+  const int ecol = wn * 32 + ech * 8;
+  const bool col_ok = ecol < p.Nout;
+  // BatchNorm partial sums live in LDS between tiles (wave-private [16][64] floats behind the staging slices):
+  // sixteen registers that would otherwise be live through the loop
+  // (accessed by inline asm like the staging slices: a compiler-visible LDS access waits for the window DMA in flight)
+  float* const sums = reinterpret_cast<float*>(smem + wrows8 * 128 + NW * 2048) + wid * 1024 + lane;
+  const uint32_t sums_lds = lds0 + wrows8 * 128 + NW * 2048 + (wid * 1024 + lane) * 4;
+  if (p.stats) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sums[e * 64] = 0.f;
+  }
+
+  // (timing probe, wave 0: cycles waiting for the window / in the MFMA loop / at the post-loop barrier / issuing the next
+  //  window / in the epilogue; tiles)
+  unsigned long long pq[6] = {0, 0, 0, 0, 0, 0};
+#define L1_NOW() (PROBE ? __builtin_readcyclecounter() : 0ull)
+  const unsigned long long pq_t0 = L1_NOW();
+  const unsigned long long pq_w0 = PROBE ? wall_clock64() : 0ull;
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  if (tile < ntiles) {
+    load_window_tab(tile * BM);
+    issue_window();
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int G0 = tile * BM;
+    const bool more = tile + (int)gridDim.x < ntiles;
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const unsigned long long q0 = L1_NOW();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned long long q1 = L1_NOW();
+    // (an opaque zero per tile: without it the compiler hoists the 36 fragment addresses of a tile out of the tile loop --
+    //  36 VGPRs beside 144 of filter and 64 of accumulators)
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    const int baseA = wm * 128 + frow + p.halo + zero;
+    // fragment n = (tap * 4 + ks) * 4 + i feeds MFMA n; six fragment slots, fragment n + 5 is read just before MFMA n
+    // issues (into the slot MFMA n - 1 has consumed): five MFMAs = 160 cycles of look-ahead on 24 registers -- a second
+    // full set (32) does not fit beside 144 of filter and 64 of accumulators
+    bf16x8 af[6];
+    auto read_frag = [&](auto N_) {
+      constexpr int n = decltype(N_)::value;
+      constexpr int t = n / 4, i = n % 4, tap = t / 4, ks = t % 4, tr = tap / 3, ts = tap % 3;
+      const int d = DGRAD ? (1 - tr) * p.Wp + (1 - ts) : (tr - 1) * p.Wp + (ts - 1);
+      const int rowA = baseA + d;
+      const int key = (rowA >> 1) & 7;                     // rows of the four m-tiles are 32 apart: same key
+      af[n % 6] = *reinterpret_cast<const bf16x8*>(smem + rowA * 128 + (((2 * ks + fh) ^ key) << 4) + i * 4096);
+    };
+    bf16x8 b8;      // the ninth tap's fragment of the current k-step (from LDS)
+    auto mfma_frag = [&](auto N_) {
+      constexpr int n = decltype(N_)::value;
+      constexpr int t = n / 4, i = n % 4;
+      if constexpr (t / 4 == 8) {
+        if constexpr (i == 0) b8 = *reinterpret_cast<const bf16x8*>(wtap8 + (wn * 4 + t % 4) * 1024 + lane * 16);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8, af[n % 6], acc[i], 0, 0, 0);
+      } else {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[t / 4][t % 4], af[n % 6], acc[i], 0, 0, 0);
+      }
+    };
+    read_frag(WinInt<0>{}); read_frag(WinInt<1>{}); read_frag(WinInt<2>{}); read_frag(WinInt<3>{}); read_frag(WinInt<4>{});
+    win_unroll<0, 144>([&](auto N_) {
+      constexpr int n = decltype(N_)::value;
+      if constexpr (n + 5 < 144) read_frag(WinInt<n + 5>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_frag(N_);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // every table value of the epilogue (output pixels) and of the next window in ONE burst, issued before the barrier (its
+    // wait hides their latency) and consumed -- pinned by an empty asm -- before the window DMA goes out: vmcnt counts in
+    // order, so a load issued behind the DMA burst cannot be used before the whole window has landed
+    uint32_t ot[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      ot[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, erow * 4, (G0 + wm * 128 + q * 16 + WIN_RASTER_MARGIN) * 4, 0);
+    if (more) load_window_tab(G0 + (int)gridDim.x * BM);
+    // the tile rounded to bf16: 32 registers instead of 64 while the table values are live (a spilled table value comes back
+    // through a scratch load in front of its DMA instruction -- and waits for the previous one to land)
+    uint32_t pkacc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pkacc[i][2 * g] = pack_bf16x2(acc[i][4 * g], acc[i][4 * g + 1]);
+        pkacc[i][2 * g + 1] = pack_bf16x2(acc[i][4 * g + 2], acc[i][4 * g + 3]);
+      }
+    // every wave is done with this tile's window: the next tile's goes out now and lands underneath the epilogue
+    const unsigned long long q2 = L1_NOW();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned long long q3 = L1_NOW();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(ot[q]));
+    if (more) issue_window();
+    const unsigned long long q4 = L1_NOW();
+    // ---- epilogue, wave-private: a 32-pixel x 32-channel block at a time through this wave's 2 KB of LDS (inline-asm LDS
+    //      accesses: see above)
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t v;
+        v.x = pkacc[i][2 * g];
+        v.y = pkacc[i][2 * g + 1];
+        win_lds_write_b64(stage_lds + frow * 64 + ((g ^ ((frow >> 2) & 3)) << 4) + fh * 8, v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private: no barrier
+      u32x4_t pkv[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int r = erow + 16 * it;
+        pkv[it] = win_lds_read_b128(stage_lds + r * 64 + ((ech ^ ((r >> 2) & 3)) << 4));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pkv[0]), "+v"(pkv[1])::"memory");
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const uint32_t t = ot[2 * i + it];
+        if (t && col_ok) {
+          const uint4 pk = make_uint4(pkv[it].x, pkv[it].y, pkv[it].z, pkv[it].w);
+          *reinterpret_cast<uint4*>(p.dst + (size_t)(t - 1) * p.Nout + ecol) = pk;
+          if (p.stats) {
+            float q[8];
+            unpack8(pk, q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+          }
+        }
+      }
+    }
+    if (p.stats) {      // lane-private addresses: plain read-modify-write (in two halves: registers)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float old[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(old[e]) : "v"(sums_lds + h * 2048), "n"(e * 256) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7])
+                     :: "memory");
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = old[e] + (h == 0 ? s1[e] : s2[e]);
+          asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(sums_lds + h * 2048), "v"(a), "n"(e * 256) : "memory");
+        }
+      }
+    }
+    if (PROBE) {
+      pq[0] += q1 - q0; pq[1] += q2 - q1; pq[2] += q3 - q2; pq[3] += q4 - q3; pq[4] += L1_NOW() - q4; pq[5] += 1;
+    }
+  }
+  if (PROBE && p.probe && tid == 0) {
+    unsigned long long* o = p.probe + (size_t)blockIdx.x * 16;
+    o[0] = L1_NOW() - pq_t0; o[1] = pq[0]; o[2] = pq[1]; o[3] = pq[2]; o[4] = pq[3]; o[5] = pq[5]; o[6] = pq[4];
+    o[7] = pq_w0; o[8] = wall_clock64();      // 100 MHz
+    o[9] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+  }
+#undef L1_NOW
+  if (p.stats) {
+    // one partial row per workgroup: channel group c = wn * 4 + ech lives in waves {wn, wn + 2}, lanes with lane % 4 == ech
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid >> 4, e = tid & 15;
+      const float* base = reinterpret_cast<const float*>(smem + wrows8 * 128 + NW * 2048);
+      float v = 0.f;
+      for (int w2 = 0; w2 < 2; ++w2)
+        for (int q = 0; q < 16; ++q) v += base[(w2 * 2 + (c >> 2)) * 1024 + e * 64 + q * 4 + (c & 3)];
+      const int n = c * 8 + (e & 7);
+      if (n < p.Nout) {
+        if (p.stat_slices > 0) atomicAdd(&p.stats[((size_t)(blockIdx.x % p.stat_slices) * 2 + (e >> 3)) * p.Nout + n], v);
+        else p.stats[((size_t)blockIdx.x * 2 + (e >> 3)) * p.Nout + n] = v;
+      }
+    }
+  }
+#endif   // __HIP_DEVICE_COMPILE__
+}
+
+extern "C" const uint32_t* mpr_raster_table(int B, int H, int W, long long* entries);   // runtime.cpp
 static unsigned long long* g_win_probe = nullptr;
 extern "C" int mpr_conv_debug_probe(void* buf) {   // 8 x uint64 per workgroup of the next window-kernel launches
   g_win_probe = (unsigned long long*)buf;
@@ -827,13 +1104,18 @@ static inline bool win_persistent(bool dgrad, int Nout, const void* add) {
   return !(g_win_variant & 64) && Nout <= 64 && add == nullptr && (!dgrad || (g_win_variant & 128));
 }
 
+// 64 -> <= 64 channels, no fused epilogue: the filter-in-registers kernel (variant bit 8 switches it off; comparisons)
+static inline bool win_l1(int srcC, int Nout, const void* add) {
+  return !(g_win_variant & 256) && srcC == 64 && Nout <= 64 && add == nullptr;
+}
+
 // rows of the BatchNorm partial-sum buffer the forward launch will write
 int mpr_conv_stat_slices();
 bool mpr_conv_take_prezeroed();
 int mpr_win_stat_rows(int B, int H, int W, int Nout) {
   if (mpr_conv_stat_slices() > 0) return mpr_conv_stat_slices();
   const int tiles = ceil_div(B * (H + 1) * (W + 1), 256);
-  return win_persistent(false, Nout, nullptr) ? (tiles < 512 ? tiles : 512) : tiles;
+  return (win_persistent(false, Nout, nullptr) || win_l1(64, Nout, nullptr)) ? (tiles < 512 ? tiles : 512) : tiles;
 }
 
 // src [B,H,W,srcC] (*) panel [Npad128][9*srcC] -> dst [B,H,W,Nout]  (dgrad: mirrored tap shifts)
@@ -871,6 +1153,30 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
   p.ntn = ceil_div(Nout, BN);
   const int tiles_m = ceil_div(p.Gtot, 256);
   const size_t wbytes = (size_t)((p.wrows + 7) / 8 * 8) * 128;
+  if (!bnb && win_l1(srcC, Nout, add)) {
+    long long rt_entries = 0;
+    p.rtab = mpr_raster_table(B, H, W, &rt_entries);
+    MPR_REQUIRE(p.rtab != nullptr, "conv (window, 64 channels): raster table allocation failed");
+    p.rtab_bytes = (unsigned)(rt_entries * 4);
+    p.ntn = 1;
+    const size_t lds = wbytes + 4 * 2048 + 4 * 4096 + 8192 + 1024;      // window + staging + BatchNorm partial sums + the ninth tap + sink
+    const int grid_p = tiles_m < 512 ? tiles_m : 512;
+#define MPR_L1(DG_, PR_)                                                                                               \
+  do {                                                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      hipFuncSetAttribute((const void*)conv_win_l1_kernel<DG_, PR_>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                          160 * 1024);                                                                                 \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    conv_win_l1_kernel<DG_, PR_><<<grid_p, 256, lds, st>>>(p);                                                         \
+  } while (0)
+    if (p.probe) { if (dgrad) MPR_L1(true, true); else MPR_L1(false, true); }
+    else { if (dgrad) MPR_L1(true, false); else MPR_L1(false, false); }
+#undef MPR_L1
+    MPR_LAUNCH_CHECK("conv_win_l1_kernel");
+    return MPR_OK;
+  }
   if (!bnb && win_persistent(dgrad, Nout, add)) {
     p.ntn = 1;
     const size_t lds = wbytes + 2 * 8192 + 4 * 4096;

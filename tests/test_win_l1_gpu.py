@@ -1,0 +1,45 @@
+"""64 -> (<= 64)-channel 3x3 / stride 1 convolutions on the filter-in-registers kernel (csrc/conv_win.hip: conv_win_l1_kernel,
+ResNet layer1 behind /root/reference/src/image_encoder.py:24): forward (+ BatchNorm partial sums) and the plain data gradient
+against fp32 torch on the same bf16-rounded operands and -- bit for bit -- against the shifted-window kernels it replaces
+(same products, same summation order), on ragged rasters, partial last tiles and an output width that is not 64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('B,H,W,K', [(64, 56, 56, 64), (37, 19, 23, 64), (9, 56, 40, 64), (340, 7, 7, 64), (16, 33, 12, 40),
+                                     (3, 56, 56, 64), (1, 8, 9, 8)])
+def test_l1_kernel_matches_window_kernels_and_fp32(B, H, W, K):
+    from multimodal_plankton_recognition_amd import ops, _native as N
+    C = 64
+    g = ops.ConvGeom((K, C, 3, 3), 1, 1)
+    gen = torch.Generator().manual_seed(B * 131 + W)
+    w = (torch.randn(K, C, 3, 3, generator=gen) * 0.05).to(DEV)
+    wf, wd = ops.packed_weights(w, g)
+    x = torch.randn(B, H, W, C, generator=gen).to(DEV).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, K, generator=gen).to(DEV).to(torch.bfloat16)
+    base = N.query('mpr_conv_set_window_variant', 5)
+    res = {}
+    try:
+        for name, var in (('l1', 5), ('old', 5 | 256)):
+            N.query('mpr_conv_set_window_variant', var)
+            y, st = ops.conv_fwd(x, wf, g, True)
+            dx = ops.conv_dgrad(dy, wd, g, tuple(x.shape))
+            res[name] = (y, st.double().sum(0), dx)
+    finally:
+        N.query('mpr_conv_set_window_variant', base)
+    wq = w.to(torch.bfloat16).float()
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)
+    refd = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)
+    y1, s1, d1 = res['l1']
+    y0, s0, d0 = res['old']
+    assert torch.equal(y1, y0) and torch.equal(d1, d0)
+    assert (y1.float() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item()          # one bf16 ulp of the largest value
+    assert (d1.float() - refd).abs().max().item() <= 8e-3 * refd.abs().max().item()
+    # BatchNorm partial sums of the ROUNDED output (what the apply pass normalises)
+    yq = y1.double().reshape(-1, K)
+    want = torch.stack([yq.sum(0), (yq * yq).sum(0)])
+    assert (s1 - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    assert (s0 - want).abs().max().item() <= 1e-4 * want.abs().max().item()
