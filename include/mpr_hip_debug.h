@@ -22,8 +22,13 @@ int mpr_conv_set_window(int on);
  * eligible (its padded raster costs (W+1)(H+1) / WH of the work: +31 % at 7 x 7); 0 = never, default 8; returns the previous value */
 int mpr_conv_set_window_fwd_min_width(int w);
 
-/* tile / weight-ring variant of the shifted-window kernel (tuning knob, see conv_win.hip; default 5) */
+/* tile / weight-ring variant of the shifted-window kernel (tuning knob, see conv_win.hip; default 5 | 512; bit 8: the 64 -> 64
+ * filter-in-registers kernel off, bit 9: its fused data-gradient epilogues off) */
 int mpr_conv_set_window_variant(int v);
+
+/* workgroups of the persistent 64 -> 64 filter-in-registers kernel (conv_win_l1_kernel): 512 fill the chip once; more,
+ * shorter-lived ones let a launch that starts beside another stream's kernel rebalance -- measured slower inside the step (default 512); returns the previous value */
+int mpr_conv_set_l1_grid(int workgroups);
 
 /* rows (B*P*Q) from which the LDS-DMA ring kernel replaces the register-staged one (default 16384);
  * returns the previous threshold */

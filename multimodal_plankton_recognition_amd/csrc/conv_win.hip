@@ -521,6 +521,14 @@ __device__ __forceinline__ u32x4_t win_lds_read_b128(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+__device__ __forceinline__ void win_lds_write_b128(uint32_t addr, u32x4_t v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x2_t win_lds_read_b64(uint32_t addr) {
+  u32x2_t v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
 
 // Persistent form of the 256 x 64 tile (N <= 64: ResNet layer1, whose 9-chunk loop is shorter than the tile's own
 // prologue + epilogue).  One workgroup per (CU, slot) walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...:
@@ -810,7 +818,7 @@ __device__ __forceinline__ void win_unroll(F&& f) {      // f(WinInt<I>) ... f(W
     win_unroll<I + 1, N>(f);
   }
 }
-template <bool DGRAD, bool PROBE = false>
+template <bool DGRAD, bool PROBE = false, bool ADD = false, int BNB = 0>
 __global__ __launch_bounds__(256, 2) void conv_win_l1_kernel(const WinParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = 4, BM = 256;
@@ -830,7 +838,22 @@ __global__ __launch_bounds__(256, 2) void conv_win_l1_kernel(const WinParams p) 
   //       four MFMAs in 4 of the 36 steps: with all 144 in registers the compiler spills table values around the window DMA)
   bf16x8 breg[8][4];
   unsigned char* const wtap8 = smem + wrows8 * 128 + NW * 2048 + NW * 4096;      // [wn][ks][64 lanes x 16 B]
-  unsigned char* const sink = wtap8 + 8192;                                       // 1 KB: DMA instructions past the window
+  // 1 KB behind it: the sink of DMA instructions past the window -- or, with a fused data-gradient epilogue (ADD / BNB), the
+  // BatchNorm coefficient table [mean | invstd | scale | shift][64]; the sink is then wave 0's staging slice: that epilogue
+  // issues the next window behind a barrier at its END (see there), when no staging slice is in use
+  constexpr bool FUSED = ADD || BNB != 0;
+  static_assert(!FUSED || DGRAD, "fused epilogues belong to the data gradient");
+  unsigned char* const sink = FUSED ? smem + wrows8 * 128 : wtap8 + 8192;
+  float* const coef = reinterpret_cast<float*>(wtap8 + 8192);
+  if (BNB && tid < 64) {
+    const int n = tid < p.Nout ? tid : 0;
+    coef[tid] = p.bn_mean[n];
+    coef[64 + tid] = p.bn_invstd[n];
+    if (BNB == 2) {
+      coef[128 + tid] = p.bn_scale[n];
+      coef[192 + tid] = p.bn_shift[n];
+    }
+  }
   {
     const bf16_t* wrow = p.wpk + (size_t)(wn * 32 + frow) * p.Kgpad + fh * 8;
 #pragma unroll
@@ -950,6 +973,11 @@ __global__ __launch_bounds__(256, 2) void conv_win_l1_kernel(const WinParams p) 
       mfma_frag(N_);
       __builtin_amdgcn_sched_barrier(0);
     });
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    unsigned long long q2 = 0, q3 = 0, q4 = 0;
+    if constexpr (!FUSED) {
     // every table value of the epilogue (output pixels) and of the next window in ONE burst, issued before the barrier (its
     // wait hides their latency) and consumed -- pinned by an empty asm -- before the window DMA goes out: vmcnt counts in
     // order, so a load issued behind the DMA burst cannot be used before the whole window has landed
@@ -969,19 +997,16 @@ __global__ __launch_bounds__(256, 2) void conv_win_l1_kernel(const WinParams p) 
         pkacc[i][2 * g + 1] = pack_bf16x2(acc[i][4 * g + 2], acc[i][4 * g + 3]);
       }
     // every wave is done with this tile's window: the next tile's goes out now and lands underneath the epilogue
-    const unsigned long long q2 = L1_NOW();
+    q2 = L1_NOW();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const unsigned long long q3 = L1_NOW();
+    q3 = L1_NOW();
 #pragma unroll
     for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(ot[q]));
     if (more) issue_window();
-    const unsigned long long q4 = L1_NOW();
+    q4 = L1_NOW();
     // ---- epilogue, wave-private: a 32-pixel x 32-channel block at a time through this wave's 2 KB of LDS (inline-asm LDS
     //      accesses: see above)
-    float s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1012,6 +1037,144 @@ __global__ __launch_bounds__(256, 2) void conv_win_l1_kernel(const WinParams p) 
             for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
           }
         }
+      }
+    }
+    } else {
+      // ---- fused data-gradient epilogue (skip-connection add of the UNROUNDED tile; ReLU mask + BatchNorm-backward sums of the
+      //      layer that produced the conv's input: conv_win_kernel's ADD / BNB, the same arithmetic element by element).  Its
+      //      operands -- residual, BatchNorm input, mask source: up to three maps -- are global loads that must not queue
+      //      behind the next window's DMA (vmcnt is in order), so here the window goes out at the END, behind a barrier; the
+      //      other workgroup of the CU covers the wait.  Loads of m-tile i + 1 are in flight while m-tile i is worked on.
+      q2 = q3 = q4 = L1_NOW();
+      uint32_t ot[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        ot[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_t, erow * 4, (G0 + wm * 128 + q * 16 + WIN_RASTER_MARGIN) * 4, 0);
+      // (no skip add: the tile is rounded right away -- 32 registers instead of 64 beside the operands in flight)
+      uint32_t pkacc[ADD ? 1 : 4][8];
+      if constexpr (!ADD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            pkacc[i][2 * g] = pack_bf16x2(acc[i][4 * g], acc[i][4 * g + 1]);
+            pkacc[i][2 * g + 1] = pack_bf16x2(acc[i][4 * g + 2], acc[i][4 * g + 3]);
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(pkacc[i][g]));
+      }
+      // (the residual is consumed first and single-buffered: its next pair goes out as soon as this one is in the accumulator)
+      uint4 res[2], bx[2][2], my[2][2];      // [buffer][row of the pair]
+      auto issue_res = [&](auto I_) {
+        constexpr int i = decltype(I_)::value;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const uint32_t t = ot[2 * i + it];
+          res[it] = *reinterpret_cast<const uint4*>(p.add + (size_t)(t ? t - 1 : 0u) * p.Nout + (col_ok ? ecol : 0));
+        }
+      };
+      auto issue_loads = [&](auto BUF_, auto I_) {
+        constexpr int buf = decltype(BUF_)::value, i = decltype(I_)::value;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const uint32_t t = ot[2 * i + it];
+          const size_t o = (size_t)(t ? t - 1 : 0u) * p.Nout + (col_ok ? ecol : 0);
+          if constexpr (BNB != 0) bx[buf][it] = *reinterpret_cast<const uint4*>(p.bn_x + o);
+          if constexpr (BNB == 1) my[buf][it] = *reinterpret_cast<const uint4*>(p.mask_y + o);
+        }
+      };
+      if constexpr (ADD) issue_res(WinInt<0>{});
+      issue_loads(WinInt<0>{}, WinInt<0>{});
+      win_unroll<0, 4>([&](auto I_) {
+        constexpr int i = decltype(I_)::value, buf = i & 1;
+        if constexpr (i + 1 < 4) issue_loads(WinInt<(i + 1) & 1>{}, WinInt<i + 1>{});
+        if constexpr (ADD) {
+          // the residual's two rows (this lane's 8 channels each) -> slice -> back in the accumulator's layout (lane = pixel,
+          // four consecutive channels per register group), added to the unrounded tile
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r = erow + 16 * it;
+            u32x4_t v;
+            v.x = res[it].x; v.y = res[it].y; v.z = res[it].z; v.w = res[it].w;
+            win_lds_write_b128(stage_lds + r * 64 + ((ech ^ ((r >> 2) & 3)) << 4), v);
+          }
+          if constexpr (i + 1 < 4) issue_res(WinInt<i + 1>{});
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          u32x2_t rv[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) rv[g] = win_lds_read_b64(stage_lds + frow * 64 + ((g ^ ((frow >> 2) & 3)) << 4) + fh * 8);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3])::"memory");
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            acc[i][4 * g] += bf16lo(rv[g].x); acc[i][4 * g + 1] += bf16hi(rv[g].x);
+            acc[i][4 * g + 2] += bf16lo(rv[g].y); acc[i][4 * g + 3] += bf16hi(rv[g].y);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2_t v;
+          if constexpr (ADD) {
+            v.x = pack_bf16x2(acc[i][4 * g], acc[i][4 * g + 1]);
+            v.y = pack_bf16x2(acc[i][4 * g + 2], acc[i][4 * g + 3]);
+          } else {
+            v.x = pkacc[i][2 * g];
+            v.y = pkacc[i][2 * g + 1];
+          }
+          win_lds_write_b64(stage_lds + frow * 64 + ((g ^ ((frow >> 2) & 3)) << 4) + fh * 8, v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u32x4_t pkv[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int r = erow + 16 * it;
+          pkv[it] = win_lds_read_b128(stage_lds + r * 64 + ((ech ^ ((r >> 2) & 3)) << 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pkv[0]), "+v"(pkv[1])::"memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const uint32_t t = ot[2 * i + it];
+          if (t && col_ok) {
+            uint4 pk = make_uint4(pkv[it].x, pkv[it].y, pkv[it].z, pkv[it].w);
+            if constexpr (BNB != 0) {
+              // dz = mask * q (q: the bf16-rounded gradient values), sums of dz and dz * xhat (conv_win_kernel: bnb_group)
+              float q[8], xf[8];
+              unpack8(pk, q);
+              unpack8(bx[buf][it], xf);
+              if constexpr (BNB == 1) {
+                float ym[8];
+                unpack8(my[buf][it], ym);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = ym[e] > 0.f ? q[e] : 0.f;
+              } else {
+                const float4 c0 = *reinterpret_cast<const float4*>(coef + 128 + ecol), c1 = *reinterpret_cast<const float4*>(coef + 128 + ecol + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(coef + 192 + ecol), h1 = *reinterpret_cast<const float4*>(coef + 192 + ecol + 4);
+                const float sc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = fmaf(xf[e], sc[e], sh[e]) > 0.f ? q[e] : 0.f;
+              }
+              const float4 m0 = *reinterpret_cast<const float4*>(coef + ecol), m1 = *reinterpret_cast<const float4*>(coef + ecol + 4);
+              const float4 i0 = *reinterpret_cast<const float4*>(coef + 64 + ecol), i1 = *reinterpret_cast<const float4*>(coef + 64 + ecol + 4);
+              const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, is[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                s1[e] += q[e];
+                s2[e] += q[e] * (xf[e] - mu[e]) * is[e];
+              }
+              pk = pack8(q);
+            }
+            *reinterpret_cast<uint4*>(p.dst + (size_t)(t - 1) * p.Nout + ecol) = pk;
+          }
+        }
+      });
+      // every wave is done with the window AND with its staging slice (wave 0's is the sink of the DMA below)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (more) {
+        load_window_tab(G0 + (int)gridDim.x * BM);
+        issue_window();
       }
     }
     if (p.stats) {      // lane-private addresses: plain read-modify-write (in two halves: registers)
@@ -1069,7 +1232,11 @@ extern "C" int mpr_conv_debug_probe(void* buf) {   // 8 x uint64 per workgroup o
   return 0;
 }
 static int g_win_on = 1;
-static int g_win_variant = 5;   // measured best: 256 x 128 tile on 8 waves / 2-deep weight ring (N > 64), 256 x 64 / 4-deep (N <= 64)
+// measured best: 256 x 128 tile on 8 waves / 2-deep weight ring (N > 64), 256 x 64 / 4-deep (N <= 64); bit 9 set: the fused
+// data-gradient epilogues of the 64 -> 64 kernel are OFF by default -- alone they are 27-46 us faster per launch than
+// conv_win_kernel's (bit-identical results), inside the step the three launches that take them change nothing (9.86 vs 9.81,
+// 10.03 vs 9.99 ms in two in-process A/Bs): kept, tested, not the default
+static int g_win_variant = 5 | 512;
 extern "C" int mpr_conv_set_window_variant(int v) {
   const int old = g_win_variant;
   g_win_variant = v;
@@ -1104,9 +1271,20 @@ static inline bool win_persistent(bool dgrad, int Nout, const void* add) {
   return !(g_win_variant & 64) && Nout <= 64 && add == nullptr && (!dgrad || (g_win_variant & 128));
 }
 
+// Workgroups of the persistent filter-in-registers kernel: 512 are resident at once (2 per CU), 12.7 tiles each at batch 512.
+// (More, shorter-lived workgroups -- so that a launch which starts beside another stream's kernel could rebalance -- were
+//  measured inside the training step and lose: 9.96 / 10.03 / 10.15 ms per step at 512 / 1024 / 2048; the startup of a
+//  workgroup, 32 filter loads + one exposed window, costs more than the rebalancing returns.)
+static int g_win_l1_grid = 512;
+extern "C" int mpr_conv_set_l1_grid(int workgroups) {
+  const int old = g_win_l1_grid;
+  if (workgroups > 0) g_win_l1_grid = workgroups;
+  return old;
+}
 // 64 -> <= 64 channels, no fused epilogue: the filter-in-registers kernel (variant bit 8 switches it off; comparisons)
-static inline bool win_l1(int srcC, int Nout, const void* add) {
-  return !(g_win_variant & 256) && srcC == 64 && Nout <= 64 && add == nullptr;
+// (bit 9: the fused data-gradient epilogues -- skip add, BatchNorm-backward sums -- stay on conv_win_kernel)
+static inline bool win_l1(int srcC, int Nout, bool fused) {
+  return !(g_win_variant & 256) && srcC == 64 && Nout <= 64 && (!fused || !(g_win_variant & 512));
 }
 
 // rows of the BatchNorm partial-sum buffer the forward launch will write
@@ -1115,7 +1293,8 @@ bool mpr_conv_take_prezeroed();
 int mpr_win_stat_rows(int B, int H, int W, int Nout) {
   if (mpr_conv_stat_slices() > 0) return mpr_conv_stat_slices();
   const int tiles = ceil_div(B * (H + 1) * (W + 1), 256);
-  return (win_persistent(false, Nout, nullptr) || win_l1(64, Nout, nullptr)) ? (tiles < 512 ? tiles : 512) : tiles;
+  if (win_l1(64, Nout, false)) return tiles < g_win_l1_grid ? tiles : g_win_l1_grid;
+  return win_persistent(false, Nout, nullptr) ? (tiles < 512 ? tiles : 512) : tiles;
 }
 
 // src [B,H,W,srcC] (*) panel [Npad128][9*srcC] -> dst [B,H,W,Nout]  (dgrad: mirrored tap shifts)
@@ -1153,26 +1332,32 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
   p.ntn = ceil_div(Nout, BN);
   const int tiles_m = ceil_div(p.Gtot, 256);
   const size_t wbytes = (size_t)((p.wrows + 7) / 8 * 8) * 128;
-  if (!bnb && win_l1(srcC, Nout, add)) {
+  // (skip add + BatchNorm-backward sums together stay on conv_win_kernel: beside 128 registers of filter and the unrounded
+  //  tile, three operand streams in flight spill 22-36 registers)
+  if (win_l1(srcC, Nout, bnb != nullptr || add != nullptr) && (dgrad || (!bnb && !add)) && !(bnb && add)) {
     long long rt_entries = 0;
     p.rtab = mpr_raster_table(B, H, W, &rt_entries);
     MPR_REQUIRE(p.rtab != nullptr, "conv (window, 64 channels): raster table allocation failed");
     p.rtab_bytes = (unsigned)(rt_entries * 4);
     p.ntn = 1;
-    const size_t lds = wbytes + 4 * 2048 + 4 * 4096 + 8192 + 1024;      // window + staging + BatchNorm partial sums + the ninth tap + sink
-    const int grid_p = tiles_m < 512 ? tiles_m : 512;
-#define MPR_L1(DG_, PR_)                                                                                               \
+    const size_t lds = wbytes + 4 * 2048 + 4 * 4096 + 8192 + 1024;      // window + staging + partial sums + the ninth tap + sink / coefficients
+    const int grid_p = tiles_m < g_win_l1_grid ? tiles_m : g_win_l1_grid;
+#define MPR_L1(DG_, PR_, ADD_, BNB_)                                                                                   \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
-      hipFuncSetAttribute((const void*)conv_win_l1_kernel<DG_, PR_>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                          160 * 1024);                                                                                 \
+      hipFuncSetAttribute((const void*)conv_win_l1_kernel<DG_, PR_, ADD_, BNB_>,                                       \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                     \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
-    conv_win_l1_kernel<DG_, PR_><<<grid_p, 256, lds, st>>>(p);                                                         \
+    conv_win_l1_kernel<DG_, PR_, ADD_, BNB_><<<grid_p, 256, lds, st>>>(p);                                             \
   } while (0)
-    if (p.probe) { if (dgrad) MPR_L1(true, true); else MPR_L1(false, true); }
-    else { if (dgrad) MPR_L1(true, false); else MPR_L1(false, false); }
+    if (bnb || add) {
+      const int mm = bnb ? p.mask_mode : 0;
+      if (add) { if (mm == 1) MPR_L1(true, false, true, 1); else if (mm == 2) MPR_L1(true, false, true, 2); else MPR_L1(true, false, true, 0); }
+      else     { if (mm == 1) MPR_L1(true, false, false, 1); else MPR_L1(true, false, false, 2); }
+    } else if (p.probe) { if (dgrad) MPR_L1(true, true, false, 0); else MPR_L1(false, true, false, 0); }
+    else { if (dgrad) MPR_L1(true, false, false, 0); else MPR_L1(false, false, false, 0); }
 #undef MPR_L1
     MPR_LAUNCH_CHECK("conv_win_l1_kernel");
     return MPR_OK;

@@ -75,7 +75,12 @@ def test_block_chain_fused_vs_unfused_vs_oracle(specs, shape):
             res[fused] = (out.detach().float().cpu(), xd.grad.float().cpu(),
                           {n: p.grad.detach().float().cpu() for n, p in blocks.named_parameters()})
         assert torch.equal(res[True][0], res[False][0])
-        assert rel_l2(res[True][1], res[False][1]) < 2e-3
+        # (fused and unfused paths add the same BatchNorm-backward terms in a different ORDER: conv_win_kernel's epilogue happens
+        #  to reproduce the reduce pass bit for bit on these tiny maps; the 64-channel filter-in-registers kernel of round 3 keeps
+        #  per-lane partial sums -- 1e-5 apart -- and the bf16 roundings downstream turn that into isolated 1-ulp flips:
+        #  2.3e-3 measured on the three-block 64-channel chain.  The gradient map dz itself is bit-identical between the two
+        #  kernels: tests/test_win_l1_gpu.py)
+        assert rel_l2(res[True][1], res[False][1]) < 4e-3
         for n in res[False][2]:
             assert rel_l2(res[True][2][n], res[False][2][n]) < 5e-3, n
         # oracle (bf16-storage emulation)

@@ -43,3 +43,50 @@ def test_l1_kernel_matches_window_kernels_and_fp32(B, H, W, K):
     want = torch.stack([yq.sum(0), (yq * yq).sum(0)])
     assert (s1 - want).abs().max().item() <= 1e-4 * want.abs().max().item()
     assert (s0 - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+@pytest.mark.parametrize('B,H,W', [(150, 19, 23), (30, 56, 40), (1400, 7, 7), (11, 56, 56)])
+def test_l1_fused_data_gradient_epilogues_match_conv_win_kernel(B, H, W):
+    """Skip add of the unrounded tile, ReLU mask + BatchNorm-backward sums (both mask modes): the gradient bit for bit, the sums
+    to summation order, against conv_win_kernel's ADD / BNB epilogues (mpr_conv_set_window_variant bit 9)."""
+    from multimodal_plankton_recognition_amd import ops, _native as N
+    C = K = 64
+    g = ops.ConvGeom((K, C, 3, 3), 1, 1)
+    gen = torch.Generator().manual_seed(B + W)
+    w = (torch.randn(K, C, 3, 3, generator=gen) * 0.05).to(DEV)
+    _, wd = ops.packed_weights(w, g)
+    dy = torch.randn(B, H, W, K, generator=gen).to(DEV).to(torch.bfloat16)
+    bn_x = torch.randn(B, H, W, C, generator=gen).to(DEV).to(torch.bfloat16)
+    res = torch.randn(B, H, W, C, generator=gen).to(DEV).to(torch.bfloat16)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=gen) * 0.3).to(DEV)
+    xf = bn_x.float().reshape(-1, C)
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+
+    class St:
+        pass
+    st = St()
+    st.mean, st.invstd = mean.contiguous(), (var + 1e-5).rsqrt().contiguous()
+    st.scale = (gamma * st.invstd).contiguous()
+    st.shift = (beta - mean * st.scale).contiguous()
+    mask_y = torch.relu(xf * st.scale + st.shift + res.float().reshape(-1, C)).to(torch.bfloat16).reshape(B, H, W, C)
+    cases = [lambda: (ops.conv_dgrad(dy, wd, g, (B, H, W, C), add=res), None),
+             lambda: ops.conv_dgrad_bn(dy, wd, g, (B, H, W, C), bn_x, st, 2),
+             lambda: ops.conv_dgrad_bn(dy, wd, g, (B, H, W, C), bn_x, st, 1, mask_y=mask_y)]
+    base = N.query('mpr_conv_set_window_variant', 5)
+    arena, ops.SLICE_ARENA = ops.SLICE_ARENA, False
+    try:
+        for fn in cases:
+            out = []
+            for var in (5, 5 | 512):
+                N.query('mpr_conv_set_window_variant', var)
+                r = fn()
+                assert r is not None
+                out.append((r[0].clone(), None if r[1] is None else r[1].double().sum(0)))
+            (d1, s1), (d0, s0) = out
+            assert torch.equal(d1, d0)
+            if s1 is not None:
+                assert (s1 - s0).abs().max().item() <= 1e-3 * s0.abs().max().item()
+    finally:
+        N.query('mpr_conv_set_window_variant', base)
+        ops.SLICE_ARENA = arena
