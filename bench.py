@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 CARD = os.path.join(ROOT, 'model_cards', 'resnet18_cnn_2_512_clip.yaml')
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+C3_STEP_TFLOP = 5.36                    # algorithmic work of one batch-512 C3 step
 
 
 def synthetic_batch(B, T, device, seed, transformer=False):
@@ -69,7 +70,9 @@ def isolated_conv_rate(B, dev):
             'avg_launch_us': round(tot_ms * 1e3 / 8, 2)}
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+if not os.path.exists(PMC_FILE):
+    PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
 
 
 def pmc_traffic(family):
@@ -244,12 +247,12 @@ def main():
                     'algorithmic_bytes_per_launch': round(algo / max(n, 1)),
                     'traffic': pmc_traffic(pmc_key) if c3 else None}
 
-        fam = {'win_fwd': family([6], 'conv_win_kernel / conv_win_persist_kernel, forward (3x3 stride 1)', 'win_fwd'),
+        fam = {'win_fwd': family([6], 'conv_win_kernel / conv_win_l1_kernel (64 channels: filter in registers), forward (3x3 stride 1)', 'win_fwd'),
                'win_dgrad': family([7], 'conv_win_kernel, data gradient (+ fused skip add, ReLU mask, BatchNorm-backward sums)', 'win_dgrad'),
                'dma_fwd_dgrad': family([0, 1], 'conv_igemm_dma_kernel (stride-2 3x3 and 1x1 convolutions forward + data gradient, layer4 3x3 forward)', 'dma_fwd_dgrad'),
                'wgrad_win': family([8], 'conv_wgrad_win_kernel (3x3 stride 1 weight gradients)', 'wgrad_win'),
                'wgrad_dma': family([2], 'conv_wgrad_dma_kernel (other weight gradients)', 'wgrad_dma')}
-        dom = family([6, 7], 'conv_win_kernel (shifted-window implicit-GEMM conv: the forward passes of 10 and the data gradients '
+        dom = family([6, 7], 'conv_win_kernel / conv_win_l1_kernel (shifted-window implicit-GEMM conv: the forward passes of 10 and the data gradients '
                              "of 13 of ResNet-18's 20 convolutions, about three quarters of its forward + data-gradient FLOPs)", 'win_fwd_dgrad')
         if dom['launches'] == 0:
             # cards without 3x3 / stride-1 convolutions (transformer encoders: every linear is a one-tap implicit GEMM)
@@ -272,11 +275,19 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['achieved'], 'peak': MFMA_BF16_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': dom['frac'], 'traffic': dom['traffic'],
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, '
-                                         'profiles/r02_pmc_traffic.json)',
+                                         f'profiles/{os.path.basename(PMC_FILE)})',
                          'algorithmic_bytes_per_launch': dom['algorithmic_bytes_per_launch'],
                          'launches': dom['launches'], 'avg_launch_us': dom['avg_launch_us'],
                          'share_of_step_time': dom['share_of_step_time'],
                          'families': fam,
+                         # so that the headline cannot look better than the step: the largest consumer of step time by launch
+                         # duration (the window weight gradients, on their side stream) and the whole step against the same peak
+                         'largest_time_consumer': {k: fam['wgrad_win'][k] for k in ('kernel', 'achieved', 'frac', 'launches',
+                                                                                    'avg_launch_us', 'share_of_step_time')},
+                         'whole_step': ({'achieved': round(C3_STEP_TFLOP * B / 512 / ms_per_step * 1e3, 2), 'unit': 'TFLOP/s',
+                                         'frac': round(C3_STEP_TFLOP * B / 512 / ms_per_step * 1e3 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                         'work': f'{C3_STEP_TFLOP} TFLOP per batch-512 step (SURVEY 8d: 10.47 GFLOP per sample)'}
+                                        if c3 else None),
                          'alone': isolated_conv_rate(B, dev) if c3 else None,
                          'note': 'achieved / avg_launch_us: hipEvent-timed on the launch stream INSIDE every 4th timed step, i.e. '
                                  'while the profile branch and the weight-gradient kernels run beside it on other streams; '

@@ -43,12 +43,15 @@ def family(pred):
 
 
 def win(k, dgrad):
-    """conv_win_kernel<WM, WN, TM, TN, STAGES, DGRAD, ...> / conv_win_persist_kernel<DGRAD>"""
+    """conv_win_kernel<WM, WN, TM, TN, STAGES, DGRAD, ...> / conv_win_persist_kernel<DGRAD> / conv_win_l1_kernel<DGRAD, ...>"""
     m = re.match(r'conv_win_kernel<([^>]*)>', k)
     if m:
         return m.group(1).split(',')[5].strip() == ('true' if dgrad else 'false')
     m = re.match(r'conv_win_persist_kernel<([^>]*)>', k)
-    return bool(m) and m.group(1).strip() == ('true' if dgrad else 'false')
+    if m:
+        return m.group(1).strip() == ('true' if dgrad else 'false')
+    m = re.match(r'conv_win_l1_kernel<([^>]*)>', k)      # <DGRAD, PROBE, ADD, BNB>
+    return bool(m) and m.group(1).split(',')[0].strip() == ('true' if dgrad else 'false')
 
 
 families = {'win_fwd': family(lambda k: win(k, False)), 'win_dgrad': family(lambda k: win(k, True)),
