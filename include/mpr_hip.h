@@ -89,6 +89,12 @@ int mpr_conv_dgrad_s2_bn(const void* dy, const void* w_dgrad, void* dz, const vo
 int mpr_conv_wgrad(const void* x, const void* dy, float* workspace /* K*R*S*C floats */, float* dw_oihw /* may be NULL */,
                    int accumulate, int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph,
                    int pw, void* stream);
+/* The same with every per-launch choice as an ARGUMENT instead of a setter armed "for the next call" (round 3; the Python
+ * layer uses this form): `scratch` (scratch_floats floats, may be NULL) is lent to THIS call for the window kernel's partial
+ * tiles; target_wgs <= 0: the library default; kernel: -1 / 1 = sliding-window kernel where the geometry allows, 0 = never */
+int mpr_conv_wgrad_ex(const void* x, const void* dy, float* workspace /* K*R*S*C floats */, float* dw_oihw /* may be NULL */,
+                      int accumulate, int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw,
+                      void* scratch /* may be NULL */, long long scratch_floats, int target_wgs, int kernel, void* stream);
 
 /* Data gradient of a 3x3 / stride 1 / pad 1 convolution whose INPUT was the output of BatchNorm (+ ReLU) -- timm
  * BasicBlock / _BasicBlock (src/profile_encoder.py:132-148: conv -> BN -> ReLU -> conv -> BN -> add -> ReLU): the epilogue

@@ -468,6 +468,21 @@ int mpr_conv_set_wgrad_dma_min_pixels(int pixels) {   // tuning / test knob; ret
 
 // dw_oihw[K,C,R,S] (fp32) = sum over the batch;  workspace: K*R*S*C floats (zeroed here).
 // dw_oihw may be NULL: see below.
+// Every choice of a launch as an ARGUMENT (round 3; ops.py uses this form: nothing process-global is set "for the next call"):
+//   scratch / scratch_floats: device floats lent to THIS call for the window kernel's partial tiles (NULL: fp32 atomics);
+//   target_wgs: workgroup-count target of the split over pixels (<= 0: the library default / mpr_conv_set_wgrad_target_wgs);
+//   kernel: -1 = by geometry, 0 = never the sliding-window kernel (gather / register-staged), 1 = as -1.
+static int wgrad_impl(const void* x, const void* dy, float* workspace, float* dw_oihw, int accumulate, int B, int H, int W,
+                      int C, int K, int R, int S, int sh, int sw, int ph, int pw, float* scratch, long long scratch_floats,
+                      int target_wgs, int kernel, void* stream);
+
+int mpr_conv_wgrad_ex(const void* x, const void* dy, float* workspace, float* dw_oihw, int accumulate, int B, int H, int W,
+                      int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* scratch, long long scratch_floats,
+                      int target_wgs, int kernel, void* stream) {
+  return wgrad_impl(x, dy, workspace, dw_oihw, accumulate, B, H, W, C, K, R, S, sh, sw, ph, pw, (float*)scratch,
+                    scratch ? scratch_floats : 0, target_wgs, kernel, stream);
+}
+
 int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oihw, int accumulate, int B,
                    int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
   // the one-shot scratch loan (mpr_conv_set_wgrad_scratch) belongs to THIS call whatever happens next: taken before any
@@ -475,6 +490,14 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   float* scratch = nullptr;
   long long scratch_floats = 0;
   mpr_wgw_take_scratch(&scratch, &scratch_floats);
+  return wgrad_impl(x, dy, workspace, dw_oihw, accumulate, B, H, W, C, K, R, S, sh, sw, ph, pw, scratch, scratch_floats, 0,
+                    -1, stream);
+}
+
+static int wgrad_impl(const void* x, const void* dy, float* workspace, float* dw_oihw, int accumulate, int B, int H, int W,
+                      int C, int K, int R, int S, int sh, int sw, int ph, int pw, float* scratch, long long scratch_floats,
+                      int target_wgs, int kernel, void* stream) {
+  const int target = target_wgs > 0 ? target_wgs : g_wgrad_target_wgs;
   MPR_REQUIRE(x && dy && workspace, "mpr_conv_wgrad: null pointer");
   MPR_REQUIRE(C % 8 == 0 && K % 8 == 0, "mpr_conv_wgrad: C (%d) and K (%d) must be multiples of 8", C, K);
   const int P = (H + 2 * ph - R) / sh + 1, Q = (W + 2 * pw - S) / sw + 1;
@@ -496,11 +519,11 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
   // weight); `accumulate` then adds into what is there instead of zeroing it first
   if (dw_oihw || !accumulate) MPR_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)K * p.Ng, st));
 
-  if (mpr_wgw_eligible(p.Mpix, H, W, C, K, R, S, sh, sw, ph, pw, g_wgrad_dma_min_pix)) {
+  if (kernel != 0 && mpr_wgw_eligible(p.Mpix, H, W, C, K, R, S, sh, sw, ph, pw, g_wgrad_dma_min_pix)) {
     // 3x3 / stride 1 / pad 1: sliding-window kernel (conv_wgrad_win.hip); profiler kind 8
     void* tok = mpr_prof_begin(8, 2.0 * (double)p.Mpix * (double)K * (double)p.Ng, st);
     mpr_prof_bytes(tok, (double)p.x_bytes + (double)p.dy_bytes + 4.0 * K * p.Ng);
-    const int rc = mpr_wgw_launch(x, dy, workspace, B, H, W, C, K, g_wgrad_target_wgs, scratch, scratch_floats, st);
+    const int rc = mpr_wgw_launch(x, dy, workspace, B, H, W, C, K, target, scratch, scratch_floats, st);
     mpr_prof_end(tok, st);
     if (rc != MPR_OK) return rc;
     if (dw_oihw) {
@@ -527,7 +550,7 @@ int mpr_conv_wgrad(const void* x, const void* dy, float* workspace, float* dw_oi
     const int total_chunks = ceil_div(p.Mpix, 64);
     // ONE round of workgroups: 2 fit a CU (64 KB of LDS each), 512 slots on the chip.  A grid of 768 (1.5 rounds) left
     // the second round half empty -- measured: 360-400 of 512 slots alive on average, 25 % of the kernel time.
-    int nsplit = g_wgrad_target_wgs / tiles;
+    int nsplit = target / tiles;
     while (nsplit > 8 && (p.ntm * nsplit) % 8) --nsplit;                          // whole XCD groups of 8 (no padding WGs)
     if (nsplit > ceil_div(total_chunks, 4)) nsplit = ceil_div(total_chunks, 4);   // >= 4 chunks per split
     if (nsplit < 1) nsplit = 1;

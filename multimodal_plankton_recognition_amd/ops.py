@@ -323,17 +323,20 @@ WGRAD_SCRATCH_FLOATS = 20 * 1024 * 1024      # 80 MB per stream: 256 workgroups 
 _wgrad_scratch = {}                          # raw stream handle -> scratch tensor
 
 
-def _wgrad_call(x, dy, out, dw, accumulate, B, H, W, C, K, R, S, sh, sw, ph, pw, stream_handle=None):
-    """mpr_conv_wgrad, lending the sliding-window kernel per-stream scratch for its partial tiles (plain stores + one
-    reduction pass instead of 75 MB of fp32 atomics per launch).  The loan is one-shot: consecutive launches on one
-    stream reuse the buffer in stream order, launches on different streams have different buffers."""
+def _wgrad_call(x, dy, out, dw, accumulate, B, H, W, C, K, R, S, sh, sw, ph, pw, stream_handle=None, choice=None):
+    """mpr_conv_wgrad_ex: every per-launch choice travels as an argument (nothing process-global is armed "for the next
+    call").  `choice` = (kernel, workgroup target) of the tuner, None = the library's defaults.  The sliding-window kernel is
+    lent per-stream scratch for its partial tiles (plain stores + one reduction pass instead of 75 MB of fp32 atomics per
+    launch): consecutive launches on one stream reuse the buffer in stream order, different streams have different buffers."""
+    buf = None
     if (R, S, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and C % 64 == 0 and K % 64 == 0 and USE_WGRAD_SCRATCH:
         h = stream_handle if stream_handle is not None else N.stream(x.device.index)
         buf = _wgrad_scratch.get(h)
         if buf is None:
             buf = _wgrad_scratch[h] = torch.empty(WGRAD_SCRATCH_FLOATS, dtype=F32, device=x.device)
-        N.query('mpr_conv_set_wgrad_scratch', buf.data_ptr(), buf.numel())
-    N.call('mpr_conv_wgrad', x, dy, out, dw, accumulate, B, H, W, C, K, R, S, sh, sw, ph, pw, stream_handle=stream_handle)
+    kernel, target = (-1, 0) if choice is None else (int(choice[0]), int(choice[1]))
+    N.call('mpr_conv_wgrad_ex', x, dy, out, dw, accumulate, B, H, W, C, K, R, S, sh, sw, ph, pw, buf,
+           buf.numel() if buf is not None else 0, target, kernel, stream_handle=stream_handle)
 
 
 USE_WGRAD_SCRATCH = os.environ.get('MPR_WGRAD_SCRATCH', '1') != '0'
@@ -355,22 +358,18 @@ def _tune_wgrad(x, dy, g, key):
     cands = ([(1, 160), (1, 192), (1, 256), (1, 512)] if win_ok else []) + \
             [(0, 256), (0, 384), (0, 512), (0, 768), (0, 1024)]
     best, best_s = (0, 768), None
-    old_win = N.query('mpr_conv_set_wgrad_window', 1)
     for win, tg in cands:
-        N.query('mpr_conv_set_wgrad_window', win)
-        N.query('mpr_conv_set_wgrad_target_wgs', tg)
-        _wgrad_call(x, dy, ws, None, 0, B, H, W, C, g.K, *g.tail)
+        _wgrad_call(x, dy, ws, None, 0, B, H, W, C, g.K, *g.tail, choice=(win, tg))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(3):
-            _wgrad_call(x, dy, ws, None, 1, B, H, W, C, g.K, *g.tail)
+            _wgrad_call(x, dy, ws, None, 1, B, H, W, C, g.K, *g.tail, choice=(win, tg))
         b.record()
         b.synchronize()
         slots = 256 if win else 512
         score = a.elapsed_time(b) * min(tg, slots) / slots
         if best_s is None or score < best_s:
             best, best_s = (win, tg), score
-    N.query('mpr_conv_set_wgrad_window', old_win)
     _wgrad_split[key] = best
     if _WGRAD_PLAN:
         import json
@@ -383,29 +382,22 @@ def conv_wgrad(x, dy, g, weight):
     """Gradient of `weight` (a tensor: its layout and, if the optimizer installed one, its gradient memory are
     used; or a plain shape -> contiguous OIHW result).  Returns None when it accumulated into grad_target(weight)."""
     B, H, W, C = _geom(x)
-    restore_win = None
+    choice = None                                      # (kernel, workgroup target) of THIS launch: an argument, not a setter
     if _FIXED_WGRAD_WGS:
-        N.query('mpr_conv_set_wgrad_target_wgs', _FIXED_WGRAD_WGS)
+        choice = (-1, _FIXED_WGRAD_WGS)
     elif AUTOTUNE and C % 64 == 0 and g.K % 64 == 0 and dy.numel() // g.K >= 16384:
         key = (B, H, W, C, g.K, *g.tail)
         choice = _wgrad_split.get(key)
         if choice is None:
             choice = _tune_wgrad(x, dy, g, key)
-        N.query('mpr_conv_set_wgrad_target_wgs', choice[1])
-        if not choice[0]:                       # the gather kernel won for this shape: window kernel off for this call
-            restore_win = N.query('mpr_conv_set_wgrad_window', 0)
-    try:
-        return _conv_wgrad(x, dy, g, weight, B, H, W, C)
-    finally:
-        if restore_win is not None:
-            N.query('mpr_conv_set_wgrad_window', restore_win)
+    return _conv_wgrad(x, dy, g, weight, B, H, W, C, choice)
 
 
-def _conv_wgrad(x, dy, g, weight, B, H, W, C):
+def _conv_wgrad(x, dy, g, weight, B, H, W, C, choice=None):
     if not torch.is_tensor(weight):
         ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
         dw = torch.empty(weight, dtype=F32, device=x.device)
-        _wgrad_call(x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail)
+        _wgrad_call(x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail, choice=choice)
         return dw
     tgt = grad_target(weight)
     if is_krsc(weight):          # the kernel's native [K][R][S][C] result IS the gradient's memory
@@ -413,7 +405,7 @@ def _conv_wgrad(x, dy, g, weight, B, H, W, C):
             if ASYNC_WGRAD:
                 cur, side = _wgrad_stream(x.device.index)
                 side.wait_stream(cur)
-                _wgrad_call(x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail, stream_handle=side.cuda_stream)
+                _wgrad_call(x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail, stream_handle=side.cuda_stream, choice=choice)
                 _note_arena_stream(x.device.index, side)
                 # the allocator must not recycle the operands under the side stream.  Tensor.record_stream would do, but a
                 # block freed with a pending foreign-stream use sits in limbo until that (low-priority, lagging) stream
@@ -427,17 +419,17 @@ def _conv_wgrad(x, dy, g, weight, B, H, W, C):
                     x.record_stream(side)
                     dy.record_stream(side)
             else:
-                _wgrad_call(x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail)
+                _wgrad_call(x, dy, tgt, None, 1, B, H, W, C, g.K, *g.tail, choice=choice)
             return None
         dw = torch.empty_strided(weight.shape, weight.stride(), dtype=F32, device=x.device)
-        _wgrad_call(x, dy, dw, None, 0, B, H, W, C, g.K, *g.tail)
+        _wgrad_call(x, dy, dw, None, 0, B, H, W, C, g.K, *g.tail, choice=choice)
         return dw
     ws = torch.empty(g.K * g.R * g.S * g.C, dtype=F32, device=x.device)
     if tgt is not None and tgt.is_contiguous():
-        _wgrad_call(x, dy, ws, tgt, 1, B, H, W, C, g.K, *g.tail)
+        _wgrad_call(x, dy, ws, tgt, 1, B, H, W, C, g.K, *g.tail, choice=choice)
         return None
     dw = torch.empty(weight.shape, dtype=F32, device=x.device)
-    _wgrad_call(x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail)
+    _wgrad_call(x, dy, ws, dw, 0, B, H, W, C, g.K, *g.tail, choice=choice)
     return dw
 
 

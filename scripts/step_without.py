@@ -34,8 +34,8 @@ def without(names):
         return real_call(fn, *a, **k)
     return call
 cases = [('default', ()),
-         ('no weight gradients', ('mpr_conv_wgrad',)),
-         ('no weight gradients, no stem weight gradient', ('mpr_conv_wgrad', 'mpr_stem_wgrad', 'mpr_stemf_bwd')),
+         ('no weight gradients', ('mpr_conv_wgrad', 'mpr_conv_wgrad_ex')),
+         ('no weight gradients, no stem weight gradient', ('mpr_conv_wgrad', 'mpr_conv_wgrad_ex', 'mpr_stem_wgrad', 'mpr_stemf_bwd')),
          ('no BatchNorm backward apply passes', ('mpr_bn_bwd_apply_fin', 'mpr_bn_bwd_apply')),
          ('no BatchNorm forward apply passes', ('mpr_bn_apply', 'mpr_bn_apply_fin', 'mpr_bn_apply_dual', 'mpr_bn_apply_dual_fin')),
          ('no SGD / repack', ('mpr_sgd_multi', 'mpr_conv_pack_weights_multi'))]
