@@ -265,6 +265,15 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+template <int V>
+struct IgInt { static constexpr int value = V; };
+template <int I, int N, class F>
+__device__ __forceinline__ void ig_unroll(F&& f) {      // f(IgInt<I>) ... f(IgInt<N-1>)
+  if constexpr (I < N) {
+    f(IgInt<I>{});
+    ig_unroll<I + 1, N>(f);
+  }
+}
 
 // BK = K depth of a ring stage: 64 (128-B tile rows) or 32 (64-B rows: half the bytes per stage, so a deeper ring /
 // more workgroups per CU fit the 160 KB -- the loop is bound by the LATENCY of the operand stream, i.e. by the bytes
@@ -517,8 +526,48 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) p.dst[0] = (bf16_t)1.f;
     return;
   }
-#pragma unroll 1
-  for (int slab = 0; slab < WM; ++slab) {
+  // The epilogue's global operands -- residual, half-resolution shortcut gradient, ReLU-mask source, BatchNorm input: up to
+  // four maps -- are loaded ONE SLAB AHEAD of their use (round 3).  Loaded inside the row loop they exposed a full memory
+  // latency per 64-row slab: the stride-2 data gradients, whose reductions are 2-8 chunks long, spent more time waiting for
+  // these loads than multiplying (layer2.0: 308 us for 59 GFLOP, 0.08 matrix-pipe utilisation).
+  constexpr int NIT = 64 / RPP;                 // rows of a slab per thread
+  const bool has_add = p.add != nullptr;
+  const bool has_even = PAR && cls == 0 && p.add_even != nullptr;
+  // (the 16-wave tile has 128 VGPRs per wave: one buffer, loaded at the top of its own slab -- under the staging and its two
+  //  barriers -- instead of a whole slab ahead)
+  constexpr int NBUF = NW >= 16 ? 1 : 2;
+  uint4 pre_add[NBUF][NIT], pre_even[NBUF][NIT], pre_my[NBUF][NIT], pre_bx[NBUF][NIT];
+  int pre_m[NBUF][NIT];                         // output pixel of the row, -1: no such row / column group
+  auto prefetch = [&](auto BUF_, int slab) {
+    constexpr int buf = decltype(BUF_)::value;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int m = m0 + slab * 64 + rr + it * RPP - mbase;
+      const bool row_ok = m < (PAR ? p.par_valid : p.M);
+      const int mc = row_ok ? m : 0;            // class-local row == pixel index of the half-resolution grid
+      if (PAR && row_ok) {     // class-local row -> pixel (b, 2*h2 + par_h, 2*w2 + par_w) of the [B, 2*Pm, 2*Qm] gradient
+        const uint32_t b = fdiv(m, p.div_pq);
+        const uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
+        const uint32_t h2 = fdiv(rem, p.div_q);
+        const uint32_t w2 = rem - h2 * p.Qm;
+        m = ((b * 2 * p.Pm + 2 * h2 + par_h) * 2 * p.Qm) + 2 * w2 + par_w;
+      }
+      const bool ok = row_ok && col_ok;
+      pre_m[buf][it] = ok ? m : -1;
+      const size_t o = (size_t)(ok ? m : 0) * p.Nout + (col_ok ? ncol : 0);     // (a safe address for rows that do not exist)
+      if (has_add) pre_add[buf][it] = *reinterpret_cast<const uint4*>(p.add + o);
+      if (has_even) pre_even[buf][it] = *reinterpret_cast<const uint4*>(p.add_even + (size_t)mc * p.Nout + (col_ok ? ncol : 0));
+      if (BNB) {
+        pre_my[buf][it] = *reinterpret_cast<const uint4*>(p.bnb_mask_y + o);
+        pre_bx[buf][it] = *reinterpret_cast<const uint4*>(p.bnb_x + o);
+      }
+    }
+  };
+  if constexpr (NBUF == 2) prefetch(IgInt<0>{}, 0);
+  ig_unroll<0, WM>([&](auto SLAB_) {
+    constexpr int slab = decltype(SLAB_)::value, buf = NBUF == 2 ? (slab & 1) : 0;
+    if constexpr (NBUF == 1) prefetch(IgInt<0>{}, slab);
+    else if constexpr (slab + 1 < WM) prefetch(IgInt<(slab + 1) & 1>{}, slab + 1);
     lds_barrier();      // ring (first pass) / previous slab fully consumed
     if (wm == slab) {
 #pragma unroll
@@ -535,32 +584,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         }
     }
     lds_barrier();
-#pragma unroll 2
-    for (int r = rr; r < 64; r += RPP) {
-      int m = m0 + slab * 64 + r - mbase;
-      bool row_ok = m < (PAR ? p.par_valid : p.M);
-      const int mc = m;          // class-local row == pixel index of the half-resolution grid
-      if (PAR && row_ok) {     // class-local row -> pixel (b, 2*h2 + par_h, 2*w2 + par_w) of the [B, 2*Pm, 2*Qm] gradient
-        const uint32_t b = fdiv(m, p.div_pq);
-        const uint32_t rem = m - b * (uint32_t)(p.Pm * p.Qm);
-        const uint32_t h2 = fdiv(rem, p.div_q);
-        const uint32_t w2 = rem - h2 * p.Qm;
-        m = ((b * 2 * p.Pm + 2 * h2 + par_h) * 2 * p.Qm) + 2 * w2 + par_w;
-      }
-      if (row_ok && col_ok) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r = rr + it * RPP;
+      const int m = pre_m[buf][it];
+      if (m >= 0) {
         const float4 lo = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32);
         const float4 hi = *reinterpret_cast<const float4*>(smem + r * CS_STRIDE + ch * 32 + 16);
         float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         const size_t o = (size_t)m * p.Nout + ncol;
-        if (p.add) {
+        if (has_add) {
           float g[8];
-          unpack8(*reinterpret_cast<const uint4*>(p.add + o), g);
+          unpack8(pre_add[buf][it], g);
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] += g[e];
         }
-        if (PAR && cls == 0 && p.add_even) {
+        if (has_even) {
           float g[8];
-          unpack8(*reinterpret_cast<const uint4*>(p.add_even + (size_t)mc * p.Nout + ncol), g);
+          unpack8(pre_even[buf][it], g);
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] += g[e];
         }
@@ -568,8 +609,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
           // dz = (mask_y > 0) * q with q the bf16-rounded gradient; sums of dz and dz * xhat
           float q[8], ym[8], xf[8];
           unpack8(pack8(f), q);
-          unpack8(*reinterpret_cast<const uint4*>(p.bnb_mask_y + o), ym);
-          unpack8(*reinterpret_cast<const uint4*>(p.bnb_x + o), xf);
+          unpack8(pre_my[buf][it], ym);
+          unpack8(pre_bx[buf][it], xf);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             q[e] = ym[e] > 0.f ? q[e] : 0.f;
@@ -577,19 +618,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
             s2[e] += q[e] * (xf[e] - bmu[e]) * bis[e];
           }
           *reinterpret_cast<uint4*>(p.dst + o) = pack8(q);
-          continue;
-        }
-        const uint4 pk = pack8(f);
-        *reinterpret_cast<uint4*>(p.dst + o) = pk;
-        if (p.stats) {
-          float q[8];
-          unpack8(pk, q);
+        } else {
+          const uint4 pk = pack8(f);
+          *reinterpret_cast<uint4*>(p.dst + o) = pk;
+          if (p.stats) {
+            float q[8];
+            unpack8(pk, q);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+            for (int e = 0; e < 8; ++e) { s1[e] += q[e]; s2[e] += q[e] * q[e]; }
+          }
         }
       }
     }
-  }
+  });
   if (p.stats) {
 #pragma unroll
     for (int o = CPR; o < 64; o <<= 1)
