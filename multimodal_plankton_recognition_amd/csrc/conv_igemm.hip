@@ -330,6 +330,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
   const int cls = PAR ? m0 / p.par_rows : 0;
   const int par_h = cls >> 1, par_w = cls & 1;
   const int mbase = cls * p.par_rows;
+  uint32_t rowpat_even = 0, rowpat_odd = 0;      // bit r * S of the filter rows with r even / odd (wave-uniform)
+  for (int r = 0; r < p.R && r * p.S < 32; ++r) {
+    if (r & 1) rowpat_odd |= 1u << (r * p.S);
+    else rowpat_even |= 1u << (r * p.S);
+  }
   uint32_t voff[A_IT], vmask[A_IT];
 #pragma unroll
   for (int j = 0; j < A_IT; ++j) {
@@ -366,6 +371,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         if (shi > slo && rhi > rlo) {
           const uint32_t cm = ((1u << shi) - 1u) & ~((1u << slo) - 1u);
           mk = cm * (p.rowpat & ((1u << (rhi * p.S)) - 1u) & ~((1u << (rlo * p.S)) - 1u));
+        }
+      } else if (p.sh == 2 && p.sw == 2) {
+        // stride 2, closed form as well (round 3: the loops below cost ~50 VALU instructions per row, 8 rows per lane in the
+        // prologue of a workgroup that lives 12 us): tap s reaches gradient column (rw - s) / 2 iff rw - s is even, >= 0 and
+        // < 2 sW -- a parity pattern AND an index range per axis
+        const int slo = max(0, rw - 2 * (p.sW - 1)), shi = min(p.S, rw + 1);
+        const int rlo = max(0, rh - 2 * (p.sH - 1)), rhi = min(p.R, rh + 1);
+        if (shi > slo && rhi > rlo) {
+          const uint32_t cm = ((1u << shi) - 1u) & ~((1u << slo) - 1u) & ((rw & 1) ? 0xAAAAAAAAu : 0x55555555u);
+          const uint32_t rows = ((rh & 1) ? rowpat_odd : rowpat_even) & ((1u << (rhi * p.S)) - 1u) & ~((1u << (rlo * p.S)) - 1u);
+          mk = cm * rows;
         }
       } else {
         uint32_t cmask = 0;
