@@ -36,3 +36,37 @@ def test_window_wgrad_matches_fp32(B, H, W, C, target):
     assert (got - ref).abs().max().item() <= 3e-6 * scale
     assert (six - ref).abs().max().item() <= 3e-6 * scale
     assert (got - six).abs().max().item() <= 3e-6 * scale
+
+
+@pytest.mark.parametrize('B,H,W,C', [(40, 28, 20, 128), (9, 56, 40, 64)])
+def test_wgrad_ex_carries_its_choices_as_arguments(B, H, W, C):
+    """mpr_conv_wgrad_ex (round 3): kernel choice, workgroup target and scratch loan are ARGUMENTS of the launch -- the
+    sliding-window kernel with partial slices, with fp32 atomics (no scratch), the gather kernel, and the library defaults all
+    give the same gradient; the process-global knobs are left untouched."""
+    from multimodal_plankton_recognition_amd import ops, _native as N
+    K = C
+    g = ops.ConvGeom((K, C, 3, 3), 1, 1)
+    gen = torch.Generator().manual_seed(7 * B + C)
+    x = torch.randn(B, H, W, C, generator=gen).to(DEV).to(torch.bfloat16)
+    dy = (torch.randn(B, H, W, K, generator=gen) * 0.1).to(DEV).to(torch.bfloat16)
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (K, C, 3, 3), dy.float().permute(0, 3, 1, 2), padding=1)
+    knobs = (N.query('mpr_conv_set_wgrad_target_wgs', 512), N.query('mpr_conv_set_wgrad_window', 1))
+    N.query('mpr_conv_set_wgrad_target_wgs', knobs[0]); N.query('mpr_conv_set_wgrad_window', knobs[1])
+    scale = ref.abs().max().item()
+
+    def run(choice, scratch=True):
+        ws = torch.empty(K * 9 * C, dtype=torch.float32, device=DEV)
+        dw = torch.empty(K, C, 3, 3, dtype=torch.float32, device=DEV)
+        old = ops.USE_WGRAD_SCRATCH
+        ops.USE_WGRAD_SCRATCH = scratch
+        try:
+            ops._wgrad_call(x, dy, ws, dw, 0, B, H, W, C, K, *g.tail, choice=choice)
+        finally:
+            ops.USE_WGRAD_SCRATCH = old
+        return dw
+
+    for choice, scratch in [(None, True), ((1, 160), True), ((1, 256), False), ((0, 256), True), ((-1, 0), True)]:
+        got = run(choice, scratch)
+        assert (got - ref).abs().max().item() <= 3e-6 * scale, (choice, scratch)
+    after = (N.query('mpr_conv_set_wgrad_target_wgs', knobs[0]), N.query('mpr_conv_set_wgrad_window', knobs[1]))
+    assert after == knobs
