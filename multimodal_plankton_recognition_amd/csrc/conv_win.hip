@@ -63,11 +63,17 @@ __device__ __forceinline__ void wait_vmcnt_win() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int V>
+struct WinI { static constexpr int value = V; };
+
 // BNB: 0 = plain; 1 = BatchNorm-backward fusion with the ReLU mask read from mask_y; 2 = ... with the mask recomputed from
 // the BatchNorm input (compile-time: the two modes keep different operands alive, and the 8-wave tile must stay under 128
 // VGPRs for its second workgroup per CU -- at one per CU nothing runs beside a workgroup's prologue and epilogue:
 // +100 us per layer2 launch, five times what the extra map read costs)
-template <int WM, int WN, int TM, int TN, int STAGES, bool DGRAD, bool ADD = false, int BNB = 0>
+// M16: the products as v_mfma_f32_16x16x32_bf16 (wave tile 64 x 64 = 4 x 4 sub-tiles): the chip holds a higher clock on this
+// shape (scripts/micro/mfma_shape.hip).  A 32-deep step needs 4 + 4 fragments of 16 x 32 -- twice the registers of the 32x32x16
+// form at the same wave tile -- so the fragments travel in PAIRS through four slots in a snake over the tile's quadrants.
+template <int WM, int WN, int TM, int TN, int STAGES, bool DGRAD, bool ADD = false, int BNB = 0, bool M16 = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win_kernel(const WinParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WM * WN, T = 64 * NW;
@@ -143,21 +149,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
           soff, 0, 0);
   };
 
-  f32x16 acc[TN][TM];
+  static_assert(!M16 || (TM == 2 && TN == 2), "the 16x16x32 form is written for 64 x 64 wave tiles");
+  f32x16 acc[M16 ? 1 : TN][M16 ? 1 : TM];
+  f32x4 acc16[M16 ? 4 : 1][M16 ? 4 : 1];      // [channel sub-tile of 16][pixel sub-tile of 16]
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+  for (int j = 0; j < (M16 ? 1 : TN); ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < (M16 ? 1 : TM); ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < (M16 ? 4 : 1); ++j)
+#pragma unroll
+    for (int i = 0; i < (M16 ? 4 : 1); ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc16[j][i][e] = 0.f;
+  const int fr16 = lane & 15, fq = lane >> 4;      // (16x16x32: lane -> row of a 16-row sub-tile, 8-channel quarter of a 32-deep step)
 
   const int frow = lane & 31, fh = lane >> 5;
   const int baseA = wm * (TM * 32) + frow + p.halo;       // window row of this lane's pixel, m-tile 0, no shift
-  uint32_t b_rd[TN][4];
+  uint32_t b_rd[M16 ? 1 : TN][M16 ? 2 : 4];      // 32x32x16: [n-tile][k-step of 16]
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+  for (int j = 0; j < (M16 ? 1 : TN); ++j)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b_rd[j][ks] = win_swz(wn * (TN * 32) + j * 32 + frow, ks * 2 + fh);
+    for (int ks = 0; ks < (M16 ? 2 : 4); ++ks) {
+      // 16x16x32: [k-step of 32] of channel sub-tile 0; sub-tile t sits 16 rows = 2048 B further with the same swizzle key
+      if constexpr (M16) b_rd[0][ks] = win_swz(wn * 64 + fr16, ks * 4 + fq);
+      else b_rd[j][ks] = win_swz(wn * (TN * 32) + j * 32 + frow, ks * 2 + fh);
+    }
 
   // (timing probe: wave 0's shader-clock sums of the loop phases; all dead code when p.probe == NULL)
   unsigned long long pr_t0 = 0, pr_wait = 0, pr_bar = 0, pr_comp = 0, pr_a = 0, pr_b = 0, pr_loop = 0, pr_rbar = 0,
@@ -207,31 +226,87 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
     const int key = (rowA >> 1) & 7;
     const unsigned char* const arow = smem + rowA * 128;
     const unsigned char* const bst = bring + (kc % STAGES) * BSTAGE;
+    if constexpr (M16) {
+      // pairs of fragments in four slots, snake over the quadrants of the 64 x 64 wave tile (Bx = channel sub-tiles 2x, 2x+1;
+      // Ax = pixel sub-tiles 2x, 2x+1; ".k" = 32-deep step k of the chunk):
+      //   q0 B0.0 A0.0 | q1 B1.0 A0.0 | q2 B1.0 A1.0 | q3 B0.0 A1.0 | q4 B0.1 A1.1 | q5 B1.1 A1.1 | q6 B1.1 A0.1 | q7 B0.1 A0.1
+      // every pair is read once per chunk (8 pair reads = the 16 ds_read_b128 of the 32x32x16 form) into the slot its
+      // predecessor has just left; 32 fragment registers as before.
+      const int rowA16 = wm * 64 + fr16 + p.halo + d;
+      const int key16 = (rowA16 >> 1) & 7;
+      const unsigned char* const arow16 = smem + rowA16 * 128;
+      bf16x8 S0[2], S1[2], S2[2], S3[2];
+      auto ldA = [&](bf16x8* s, int ia, int ks) {      // pixel sub-tiles 2 ia, 2 ia + 1
+        s[0] = *reinterpret_cast<const bf16x8*>(arow16 + (2 * ia) * 2048 + (((4 * ks + fq) ^ key16) << 4));
+        s[1] = *reinterpret_cast<const bf16x8*>(arow16 + (2 * ia + 1) * 2048 + (((4 * ks + fq) ^ key16) << 4));
+      };
+      auto ldB = [&](bf16x8* s, int jb, int ks) {      // channel sub-tiles 2 jb, 2 jb + 1
+        s[0] = *reinterpret_cast<const bf16x8*>(bst + b_rd[0][ks] + (2 * jb) * 2048);
+        s[1] = *reinterpret_cast<const bf16x8*>(bst + b_rd[0][ks] + (2 * jb + 1) * 2048);
+      };
+      auto quad = [&](const bf16x8* sb, const bf16x8* sa, auto JB_, auto IA_) {
+        constexpr int jb = decltype(JB_)::value, ia = decltype(IA_)::value;
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+          for (int di = 0; di < 2; ++di)
+            acc16[2 * jb + dj][2 * ia + di] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb[dj], sa[di], acc16[2 * jb + dj][2 * ia + di], 0, 0, 0);
+      };
+      ldA(S0, 0, 0); ldB(S1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (issued < nk) issue_next();     // (into the stage chunk kc-1 just vacated) behind the first fragment reads
+      ldB(S2, 1, 0); ldA(S3, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S1, S0, WinI<0>{}, WinI<0>{});                                   // q0: B0.0 A0.0
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S2, S0, WinI<1>{}, WinI<0>{});                                   // q1: B1.0 A0.0
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(S0, 1, 1);                                                        //     A1.1 -> S0
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S2, S3, WinI<1>{}, WinI<1>{});                                   // q2: B1.0 A1.0
+      __builtin_amdgcn_sched_barrier(0);
+      ldB(S2, 0, 1);                                                        //     B0.1 -> S2
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S1, S3, WinI<0>{}, WinI<1>{});                                   // q3: B0.0 A1.0
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(S3, 0, 1); ldB(S1, 1, 1);                                         //     A0.1 -> S3, B1.1 -> S1
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S2, S0, WinI<0>{}, WinI<1>{});                                   // q4: B0.1 A1.1
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S1, S0, WinI<1>{}, WinI<1>{});                                   // q5: B1.1 A1.1
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S1, S3, WinI<1>{}, WinI<0>{});                                   // q6: B1.1 A0.1
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S2, S3, WinI<0>{}, WinI<0>{});                                   // q7: B0.1 A0.1
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     bf16x8 af[2][TM], bfr[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(arow + i * 4096 + ((fh ^ key) << 4));
+      for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(arow + i * 4096 + ((fh ^ key) << 4));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(bst + b_rd[j][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (issued < nk) issue_next();     // (into the stage chunk kc-1 just vacated) behind the first fragment reads
-    __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < TN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(bst + b_rd[j][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (issued < nk) issue_next();     // (into the stage chunk kc-1 just vacated) behind the first fragment reads
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks < 3) {
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks < 3) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          af[nxt][i] = *reinterpret_cast<const bf16x8*>(arow + i * 4096 + (((2 * (ks + 1) + fh) ^ key) << 4));
+          for (int i = 0; i < TM; ++i)
+            af[nxt][i] = *reinterpret_cast<const bf16x8*>(arow + i * 4096 + (((2 * (ks + 1) + fh) ^ key) << 4));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(bst + b_rd[j][ks + 1]);
+          for (int j = 0; j < TN; ++j) bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(bst + b_rd[j][M16 ? 0 : ks + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[j][i], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
     if (++ts == 3) { ts = 0; ++tr; }
     if (++tap == 9) { tap = 0; tr = 0; ++cb; }
@@ -313,6 +388,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
       const unsigned long long e0 = PROBE_NOW();
       if ((wm * TM * 32) / RPASS == ep) {
         const int wrow0 = wm * TM * 32 - ep * RPASS;
+        if constexpr (M16) {
+#pragma unroll
+          for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+              const int row = wrow0 + i2 * 16 + fr16;
+              const int col = wn * 64 + j2 * 16 + 4 * fq;
+              uint2 v;
+              v.x = pack_bf16x2(acc16[j2][i2][0], acc16[j2][i2][1]);
+              v.y = pack_bf16x2(acc16[j2][i2][2], acc16[j2][i2][3]);
+              *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = v;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -322,10 +410,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
               const int row = wrow0 + i * 32 + frow;
               const int col = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
               uint2 v;
-              v.x = pack_bf16x2(acc[j][i][4 * g], acc[j][i][4 * g + 1]);
-              v.y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+              v.x = pack_bf16x2(acc[M16 ? 0 : j][M16 ? 0 : i][4 * g], acc[M16 ? 0 : j][M16 ? 0 : i][4 * g + 1]);
+              v.y = pack_bf16x2(acc[M16 ? 0 : j][M16 ? 0 : i][4 * g + 2], acc[M16 ? 0 : j][M16 ? 0 : i][4 * g + 3]);
               *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = v;
             }
+        }
       }
       win_lds_barrier();
       const unsigned long long e1 = PROBE_NOW();
@@ -397,6 +486,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
     for (int ep = 0; ep < EPA; ++ep) {
       win_lds_barrier();
       if (ep == 0) fill_coef();
+      if constexpr (M16) {
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          const int grow = wm * 64 + i2 * 16;                // this 16-row sub-tile inside the 256-row tile (wave-uniform)
+          if (grow / RPA == ep) {
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+              const int row = grow - ep * RPA + fr16;
+              const int col = wn * 64 + j2 * 16 + 4 * fq;
+              float4 v = make_float4(acc16[j2][i2][0], acc16[j2][i2][1], acc16[j2][i2][2], acc16[j2][i2][3]);
+              *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int grow = wm * (TM * 32) + i * 32;          // this 32-row m-tile inside the 256-row tile (wave-uniform)
@@ -407,10 +511,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
             for (int g = 0; g < 4; ++g) {
               const int row = grow - ep * RPA + frow;
               const int col = wn * (TN * 32) + j * 32 + 8 * g + 4 * fh;
-              float4 v = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+              float4 v = make_float4(acc[M16 ? 0 : j][M16 ? 0 : i][4 * g], acc[M16 ? 0 : j][M16 ? 0 : i][4 * g + 1],
+                                     acc[M16 ? 0 : j][M16 ? 0 : i][4 * g + 2], acc[M16 ? 0 : j][M16 ? 0 : i][4 * g + 3]);
               *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
             }
         }
+      }
       }
       win_lds_barrier();
       constexpr int NSUBA = (BNB && T == 512) ? 2 : 1;      // (as above: 128 VGPRs)
@@ -1236,7 +1342,7 @@ static int g_win_on = 1;
 // data-gradient epilogues of the 64 -> 64 kernel are OFF by default -- alone they are 27-46 us faster per launch than
 // conv_win_kernel's (bit-identical results), inside the step the three launches that take them change nothing (9.86 vs 9.81,
 // 10.03 vs 9.99 ms in two in-process A/Bs): kept, tested, not the default
-static int g_win_variant = 5 | 512;
+static int g_win_variant = 5 | 512 | 1024;
 extern "C" int mpr_conv_set_window_variant(int v) {
   const int old = g_win_variant;
   g_win_variant = v;
@@ -1388,11 +1494,12 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
     const int BNt = Nout > 64 ? 128 : 64;
     p.ntn = ceil_div(Nout, BNt);
     dim3 gridb(tiles_m * p.ntn);
-#define MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_, MM_)                                                       \
+#define MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_, MM_) do { if (g_win_variant & 1024) MPR_WINBM(WM_, WN_, TM_, TN_, ST_, ADD_, MM_, true); else MPR_WINBM(WM_, WN_, TM_, TN_, ST_, ADD_, MM_, false); } while (0)
+#define MPR_WINBM(WM_, WN_, TM_, TN_, ST_, ADD_, MM_, M16_)                                                \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
-      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, MM_>,          \
+      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, MM_, M16_>,    \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
       attr_set = true;                                                                                     \
     }                                                                                                      \
@@ -1406,60 +1513,68 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
     size_t body_ = ring_ > epi_ ? ring_ : epi_;                                                            \
     if (body_ < need_) body_ = need_;                                                                      \
     p.coef_off = (int)tab_;                                                                                \
-    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, MM_><<<gridb, 64 * WM_ * WN_, body_, st>>>(p);    \
+    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, ADD_, MM_, M16_><<<gridb, 64 * WM_ * WN_, body_, st>>>(p); \
   } while (0)
 #define MPR_WINB2(WM_, WN_, TM_, TN_, ST_, ADD_) do { if (p.mask_mode == 1) MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_, 1); else MPR_WINB(WM_, WN_, TM_, TN_, ST_, ADD_, 2); } while (0)
     if (BNt == 64) { if (add) MPR_WINB2(4, 1, 2, 2, 4, true); else MPR_WINB2(4, 1, 2, 2, 4, false); }
     else           { if (add) MPR_WINB2(4, 2, 2, 2, 2, true); else MPR_WINB2(4, 2, 2, 2, 2, false); }
 #undef MPR_WINB2
 #undef MPR_WINB
+#undef MPR_WINBM
     MPR_LAUNCH_CHECK("conv_win_kernel (BatchNorm-backward fusion)");
     return MPR_OK;
   }
   const size_t lds_pad = (g_win_variant & 16) ? 40 * 1024 : 0;   // experiment: force one workgroup per CU
   const int g_win_variant_ = g_win_variant & 15;
   dim3 grid(tiles_m * p.ntn);
-#define MPR_WIN(WM_, WN_, TM_, TN_, ST_, DG_)                                                              \
+#define MPR_WINM(WM_, WN_, TM_, TN_, ST_, DG_, M16_)                                                        \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
-      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, DG_>,                      \
+      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, DG_, false, 0, M16_>,      \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
       attr_set = true;                                                                                     \
     }                                                                                                      \
     const size_t lds = lds_pad + wbytes + (size_t)ST_ * (WN_ * TN_ * 32) * 128;                            \
-    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, DG_><<<grid, 64 * WM_ * WN_, lds, st>>>(p);                   \
+    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, DG_, false, 0, M16_><<<grid, 64 * WM_ * WN_, lds, st>>>(p);   \
   } while (0)
-#define MPR_WINA(WM_, WN_, TM_, TN_, ST_)                                                                  \
+#define MPR_WINAM(WM_, WN_, TM_, TN_, ST_, M16_)                                                           \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
-      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, true>,               \
+      hipFuncSetAttribute((const void*)conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, true, 0, M16_>,      \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
       attr_set = true;                                                                                     \
     }                                                                                                      \
     const size_t ring_ = lds_pad + wbytes + (size_t)ST_ * (WN_ * TN_ * 32) * 128;                          \
     const size_t epi_ = (size_t)((WN_ * TN_ * 32) == 64 ? 256 : 64) * ((WN_ * TN_ * 32) * 4 + 16);         \
-    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, true><<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p); \
+    conv_win_kernel<WM_, WN_, TM_, TN_, ST_, true, true, 0, M16_><<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p); \
   } while (0)
+#define MPR_WIN(WM_, WN_, TM_, TN_, ST_, DG_) MPR_WINM(WM_, WN_, TM_, TN_, ST_, DG_, false)
+#define MPR_WINA(WM_, WN_, TM_, TN_, ST_) MPR_WINAM(WM_, WN_, TM_, TN_, ST_, false)
 #define MPR_WIN2(WM_, WN_, TM_, TN_, ST_) do { if (dgrad && add) MPR_WINA(WM_, WN_, TM_, TN_, ST_); else if (dgrad) MPR_WIN(WM_, WN_, TM_, TN_, ST_, true); else MPR_WIN(WM_, WN_, TM_, TN_, ST_, false); } while (0)
+  // (variant bit 10: the default tiles as v_mfma_f32_16x16x32_bf16)
+#define MPR_WIN216(WM_, WN_, TM_, TN_, ST_) do { if (dgrad && add) MPR_WINAM(WM_, WN_, TM_, TN_, ST_, true); else if (dgrad) MPR_WINM(WM_, WN_, TM_, TN_, ST_, true, true); else MPR_WINM(WM_, WN_, TM_, TN_, ST_, false, true); } while (0)
   if (BN == 64) {
     switch (g_win_variant_) {
       case 1: MPR_WIN2(4, 1, 2, 2, 2); break;
       case 2: MPR_WIN2(4, 1, 2, 2, 3); break;
-      default: MPR_WIN2(4, 1, 2, 2, 4); break;
+      default: if (g_win_variant & 1024) MPR_WIN216(4, 1, 2, 2, 4); else MPR_WIN2(4, 1, 2, 2, 4); break;
     }
   } else {
     switch (g_win_variant_) {
       case 3: MPR_WIN2(2, 2, 4, 2, 3); break;
-      case 5: MPR_WIN2(4, 2, 2, 2, 2); break;     // 8 waves of 64 x 64: the instruction-bound pro/epilogue on twice the waves
+      case 5: if (g_win_variant & 1024) MPR_WIN216(4, 2, 2, 2, 2); else MPR_WIN2(4, 2, 2, 2, 2); break;     // 8 waves of 64 x 64
       case 6: MPR_WIN2(4, 2, 2, 2, 3); break;
       default: MPR_WIN2(2, 2, 4, 2, 2); break;
     }
   }
+#undef MPR_WIN216
 #undef MPR_WIN2
 #undef MPR_WINA
 #undef MPR_WIN
+#undef MPR_WINAM
+#undef MPR_WINM
   MPR_LAUNCH_CHECK("conv_win_kernel");
   return MPR_OK;
 }

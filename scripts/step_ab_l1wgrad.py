@@ -29,8 +29,10 @@ for _ in range(8): one_step()
 print('tuner:', {k: v for k, v in ops._wgrad_split.items()})
 base = dict(ops._wgrad_split)
 l1 = [k for k in base if k[1] == 56 and k[3] == 64 and k[4] == 64]
-settings = [('tuner', {})] + [(f'layer1 -> {tg}', {k: (1, tg) for k in l1}) for tg in (192, 256)] + \
-           [('all window -> 256', {k: (1, 256) for k, v in base.items() if v[0] == 1})]
+tgs = [int(v) for v in sys.argv[1:]]
+settings = [('tuner', {})] + ([(f'all window -> {tg}', {k: (1, tg) for k, v in base.items() if v[0] == 1}) for tg in tgs] if tgs else
+                             [(f'layer1 -> {tg}', {k: (1, tg) for k in l1}) for tg in (192, 256)] +
+                             [('all window -> 256', {k: (1, 256) for k, v in base.items() if v[0] == 1})])
 res = {n: [] for n, _ in settings}
 for rep in range(4):
     for n, over in settings:

@@ -9,6 +9,11 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
+def want_of(y, K):
+    yq = y.double().reshape(-1, K)
+    return torch.stack([yq.sum(0), (yq * yq).sum(0)])
+
+
 @pytest.mark.parametrize('B,H,W,K', [(64, 56, 56, 64), (37, 19, 23, 64), (9, 56, 40, 64), (340, 7, 7, 64), (16, 33, 12, 40),
                                      (3, 56, 56, 64), (1, 8, 9, 8)])
 def test_l1_kernel_matches_window_kernels_and_fp32(B, H, W, K):
@@ -23,7 +28,7 @@ def test_l1_kernel_matches_window_kernels_and_fp32(B, H, W, K):
     base = N.query('mpr_conv_set_window_variant', 5)
     res = {}
     try:
-        for name, var in (('l1', 5), ('old', 5 | 256)):
+        for name, var in (('l1', 5), ('old', 5 | 256), ('old16', 5 | 256 | 1024)):
             N.query('mpr_conv_set_window_variant', var)
             y, st = ops.conv_fwd(x, wf, g, True)
             dx = ops.conv_dgrad(dy, wd, g, tuple(x.shape))
@@ -36,11 +41,14 @@ def test_l1_kernel_matches_window_kernels_and_fp32(B, H, W, K):
     y1, s1, d1 = res['l1']
     y0, s0, d0 = res['old']
     assert torch.equal(y1, y0) and torch.equal(d1, d0)
+    # conv_win_kernel on v_mfma_f32_16x16x32_bf16 (variant bit 10, the default): the same 32-term groups per instruction pair
+    y6, s6, d6 = res['old16']
+    assert torch.equal(y6, y0) and torch.equal(d6, d0)
+    assert (s6 - want_of(y1, K)).abs().max().item() <= 1e-4 * want_of(y1, K).abs().max().item()
     assert (y1.float() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item()          # one bf16 ulp of the largest value
     assert (d1.float() - refd).abs().max().item() <= 8e-3 * refd.abs().max().item()
     # BatchNorm partial sums of the ROUNDED output (what the apply pass normalises)
-    yq = y1.double().reshape(-1, K)
-    want = torch.stack([yq.sum(0), (yq * yq).sum(0)])
+    want = want_of(y1, K)
     assert (s1 - want).abs().max().item() <= 1e-4 * want.abs().max().item()
     assert (s0 - want).abs().max().item() <= 1e-4 * want.abs().max().item()
 
@@ -78,15 +86,16 @@ def test_l1_fused_data_gradient_epilogues_match_conv_win_kernel(B, H, W):
     try:
         for fn in cases:
             out = []
-            for var in (5, 5 | 512):
+            for var in (5, 5 | 512, 5 | 512 | 1024):
                 N.query('mpr_conv_set_window_variant', var)
                 r = fn()
                 assert r is not None
                 out.append((r[0].clone(), None if r[1] is None else r[1].double().sum(0)))
-            (d1, s1), (d0, s0) = out
-            assert torch.equal(d1, d0)
+            (d1, s1), (d0, s0), (d6, s6) = out
+            assert torch.equal(d1, d0) and torch.equal(d6, d0)
             if s1 is not None:
                 assert (s1 - s0).abs().max().item() <= 1e-3 * s0.abs().max().item()
+                assert (s6 - s0).abs().max().item() <= 1e-3 * s0.abs().max().item()
     finally:
         N.query('mpr_conv_set_window_variant', base)
         ops.SLICE_ARENA = arena
