@@ -470,23 +470,43 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
-// dw[i] += sum over the pixel splits of part[s][i]   (float4 per thread; the slices are L2 / Infinity-Cache warm)
-__global__ __launch_bounds__(256) void wgw_reduce_kernel(const float4* __restrict__ part, int nsplit, float4* __restrict__ dw,
+// dw[i] += sum over the pixel splits of part[s][i].  A workgroup owns 256 / SL float4 columns and walks the splits on SL
+// lanes per column (layer1: 9216 columns x 160-256 splits -- one thread per column left 36 workgroups chasing a serial chain of
+// loads, 38 us per launch), partial sums meet in LDS in a fixed order (run-to-run identical).  The slices are L2 /
+// Infinity-Cache warm.
+template <int SL>
+__global__ __launch_bounds__(256) void wgw_reduce_kernel(const float4* __restrict__ part, int nsplit, float* __restrict__ dw,
                                                           int n4) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-    float4 a = dw[i];
-    int s = 0;
-    for (; s + 4 <= nsplit; s += 4) {
-      const float4 v0 = part[(size_t)s * n4 + i], v1 = part[(size_t)(s + 1) * n4 + i];
-      const float4 v2 = part[(size_t)(s + 2) * n4 + i], v3 = part[(size_t)(s + 3) * n4 + i];
+  constexpr int COLS = 256 / SL;
+  __shared__ float4 red[SL][COLS];
+  const int tid = threadIdx.x, col = tid % COLS, sl = tid / COLS;
+  const int i = blockIdx.x * COLS + col;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    int s = sl;
+    for (; s + 3 * SL < nsplit; s += 4 * SL) {
+      const float4 v0 = part[(size_t)s * n4 + i], v1 = part[(size_t)(s + SL) * n4 + i];
+      const float4 v2 = part[(size_t)(s + 2 * SL) * n4 + i], v3 = part[(size_t)(s + 3 * SL) * n4 + i];
       a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
       a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
-    for (; s < nsplit; ++s) {
+    for (; s < nsplit; s += SL) {
       const float4 v = part[(size_t)s * n4 + i];
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    dw[i] = a;
+  }
+  red[sl][col] = a;
+  __syncthreads();
+  // thread t < 4 COLS: scalar t of the workgroup's 4 COLS contiguous floats
+  for (int t = tid; t < 4 * COLS; t += 256) {
+    const size_t o = (size_t)blockIdx.x * (4 * COLS) + t;
+    if (o < (size_t)n4 * 4) {
+      const float* const r = reinterpret_cast<const float*>(&red[0][0]) + t;
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < SL; ++q) v += r[q * 4 * COLS];
+      dw[o] += v;
+    }
   }
 }
 
@@ -592,8 +612,9 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   MPR_LAUNCH_CHECK("conv_wgrad_win_kernel");
   if (p.part) {
     const int n4 = K * p.Ng / 4;
-    wgw_reduce_kernel<<<ceil_div(n4, 256) < 1024 ? ceil_div(n4, 256) : 1024, 256, 0, st>>>((const float4*)p.part, nsplit,
-                                                                                          (float4*)dw, n4);
+    if (nsplit >= 32) wgw_reduce_kernel<16><<<ceil_div(n4, 16), 256, 0, st>>>((const float4*)p.part, nsplit, dw, n4);
+    else if (nsplit >= 8) wgw_reduce_kernel<4><<<ceil_div(n4, 64), 256, 0, st>>>((const float4*)p.part, nsplit, dw, n4);
+    else wgw_reduce_kernel<1><<<ceil_div(n4, 256), 256, 0, st>>>((const float4*)p.part, nsplit, dw, n4);
     MPR_LAUNCH_CHECK("wgw_reduce_kernel");
   }
   return MPR_OK;
