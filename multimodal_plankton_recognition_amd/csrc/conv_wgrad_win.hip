@@ -81,6 +81,14 @@ template <int N>
 __device__ __forceinline__ void wgw_wait_lgkm(s16x4& a, s16x4& b, s16x4& c, s16x4& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void wgw_wait_lgkm(s16x4 (&a)[4][2], s16x4& b0, s16x4& b1) {
+  asm volatile("s_waitcnt lgkmcnt(%10)"
+               : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]),
+                 "+v"(a[3][1]), "+v"(b0), "+v"(b1)
+               : "n"(N)
+               : "memory");
+}
 template <int V>
 struct WgwInt { static constexpr int value = V; };
 
@@ -97,7 +105,16 @@ struct WgwInt { static constexpr int value = V; };
 // the pipeline runs on across chunk boundaries (the first fragments of chunk ci + 1 are read during the last k-step of
 // chunk ci: the barrier at the top of iteration ci has confirmed them).  The DMA instructions of chunk ci + 2 go out one per
 // k-step behind its first MFMA (an LDS-DMA instruction holds the wave's issue for 60-180 cycles).
-template <int KH, int PS = 1, int PRIO = 0, bool PROBE = false>
+//
+// M16 (round 3, the default): the products as v_mfma_f32_16x16x32_bf16 -- the chip holds a higher clock on that shape
+// (scripts/micro/mfma_shape.hip: +13.7 % in an LDS-fed loop) and conv_win_kernel gained 3-10 % per launch from it.  A wave's
+// tile is 4 sub-tiles of 16 output channels x 6 sub-tiles (tap s, 16 channels); a k-step is 32 pixels: 20 transposing reads
+// for 24 MFMAs of 16 cycles, the same LDS traffic per MFMA cycle as before.  The contraction index of a lane group g = lane / 16 is
+// mapped to pixels 4 g .. 4 g + 3 (first read) and 16 + 4 g .. (second read) of the step for BOTH operands, so that a half-wave
+// reads eight consecutive rows x 32 B; the 32-B units of a 64-B segment are swapped by bit 2 of the row on the DMA's source side
+// (rows r and r + 4 would otherwise meet in the same banks).  The four dy sub-tiles of a step stay in registers (double
+// buffered: the next step's arrive during this one), the six x sub-tiles pass through a four-slot ring three MFMA groups ahead.
+template <int KH, int PS = 1, int PRIO = 0, bool PROBE = false, bool M16 = false>
 __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const WgwParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(KH * PS <= 2, "twelve waves at most");
@@ -154,7 +171,8 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   auto x_off = [&](int G8) -> uint32_t {
     const int G = G8 + (lane >> 3);
     const int pc = lane & 7;
-    const int lc = (((pc >> 2) ^ ((lane >> 4) & 1)) << 2) | (pc & 3);
+    int lc = (((pc >> 2) ^ ((lane >> 4) & 1)) << 2) | (pc & 3);
+    if (M16) lc ^= ((lane >> 5) & 1) << 1;              // 32-B unit ^ bit 2 of the row
     uint32_t pix;
     return pixel_of(G, pix) ? pix * (uint32_t)(2 * p.C) + (uint32_t)((cb * 64 + lc * 8) * 2) : 0xFFFFFFF0u;
   };
@@ -172,7 +190,8 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
     const int q = I * 64 + lane;
     const int row = q / CH, pc = q % CH;
     const int key = CH == 16 ? (row & 3) : ((row >> 1) & 1);
-    const int lc = (((pc >> 2) ^ key) << 2) | (pc & 3);
+    int lc = (((pc >> 2) ^ key) << 2) | (pc & 3);
+    if (M16) lc ^= ((row >> 2) & 1) << 1;
     uint32_t pix;
     return pixel_of(ci * CHUNK + row, pix) ? pix * (uint32_t)(2 * p.K) + (uint32_t)((kt * 64 * KH + lc * 8) * 2)
                                         : 0xFFFFFFF0u;
@@ -198,27 +217,36 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   uint32_t xcol, dcol;                                         // column terms of the source offsets (- one row: the table holds pixel + 1)
   {
     const int pc = lane & 7;
-    const int lc = (((pc >> 2) ^ ((lane >> 4) & 1)) << 2) | (pc & 3);
+    int lc = (((pc >> 2) ^ ((lane >> 4) & 1)) << 2) | (pc & 3);
+    if (M16) lc ^= ((lane >> 5) & 1) << 1;
     xcol = (uint32_t)((cb * 64 + lc * 8) * 2 - 2 * p.C);
     const int pd = lane % DCH, rin = lane / DCH;
     const int key = DCH == 16 ? (rin & 3) : ((rin >> 1) & 1);
-    const int ld = (((pd >> 2) ^ key) << 2) | (pd & 3);
+    int ld = (((pd >> 2) ^ key) << 2) | (pd & 3);
+    // (bit 2 of the dy row: 8 rows per instruction at 128-B rows; 4 at 256-B rows, where it is the parity of the instruction
+    //  index wid + j * NW -- NW is even)
+    static_assert(DCH == 8 || NW % 2 == 0, "the row bit of a dy piece must not depend on the piece");
+    if (M16) ld ^= (DCH == 8 ? (rin >> 2) & 1 : wid & 1) << 1;
     dcol = (uint32_t)((kt * 64 * KH + ld * 8) * 2 - 2 * p.K);
   }
-  uint32_t t[NP];
+  // (raw table values t[] and converted offsets tc[] in SEPARATE registers: with the conversion in place, a wave that fires its
+  //  burst in the later slot found "t[J] may have a load pending" on the path through the earlier slot's reload -- the two
+  //  slots exclude each other, which the compiler's wait insertion cannot know -- and got s_waitcnt vmcnt(0) in front of every
+  //  DMA instruction of the burst: each waited for the previous one to LAND)
+  uint32_t t[NP], tc[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) t[j] = 0;
+  for (int j = 0; j < NP; ++j) { t[j] = 0; tc[j] = 0; }
   // piece J of chunk ci (J < XC_IT: a group of eight x rows; else a kilobyte of dy rows): fire its DMA from the offsets in t[J]
   auto fire_piece = [&](auto J_, int ci) {
     constexpr int J = decltype(J_)::value;
     if constexpr (J < XC_IT) {
       const int I = wid + J * NW;
-      if ((CHUNK / 8) % NW == 0 || I < CHUNK / 8) fire_x8(ci * CHUNK + p.halo8 + 8 * I, t[J]);
+      if ((CHUNK / 8) % NW == 0 || I < CHUNK / 8) fire_x8(ci * CHUNK + p.halo8 + 8 * I, tc[J]);
     } else if constexpr (J < NP) {
       const int I = wid + (J - XC_IT) * NW;
       if (D_INSTR % NW == 0 || I < D_INSTR)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rs_d, (__attribute__((address_space(3))) void*)(dyst + (ci % NST) * DSTAGE + I * 1024), 16, t[J], 0, 0, 0);
+            rs_d, (__attribute__((address_space(3))) void*)(dyst + (ci % NST) * DSTAGE + I * 1024), 16, tc[J], 0, 0, 0);
     }
   };
   // ... and load its table value for chunk ci
@@ -237,21 +265,29 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   auto convert_pieces = [&]() {
 #pragma unroll
     for (int j = 0; j < NP; ++j)
-      t[j] = t[j] ? __umul24(t[j], (uint32_t)(2 * (j < XC_IT ? p.C : p.K))) + (j < XC_IT ? xcol : dcol) : 0xFFFFFFF0u;
+      tc[j] = t[j] ? __umul24(t[j], (uint32_t)(2 * (j < XC_IT ? p.C : p.K))) + (j < XC_IT ? xcol : dcol) : 0xFFFFFFF0u;
   };
 
-  f32x16 acc[2][3];     // [m-tile of 32 output channels][tap s]
+  f32x16 acc[M16 ? 1 : 2][M16 ? 1 : 3];     // [m-tile of 32 output channels][tap s]
+  f32x4 acc16[M16 ? 4 : 1][M16 ? 6 : 1];    // [sub-tile of 16 output channels][tap s, channel sub-tile]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < (M16 ? 1 : 2); ++i)
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < (M16 ? 1 : 3); ++s)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][s][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (M16 ? 4 : 1); ++i)
+#pragma unroll
+    for (int s = 0; s < (M16 ? 6 : 1); ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc16[i][s][e] = 0.f;
 
   // transposing-read lane geometry (conv_wgrad.hip): a 16-lane group reads a 4 (pixel) x 16 (column) block
   const int g16 = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
-  const int rowl = 8 * (g16 >> 1) + lq;                        // pixel row inside a 16-deep k-step (+4: second read)
-  const int inseg = (16 * (g16 & 1) + 4 * lp) * 2;             // byte inside a 64-B segment
+  // 32x32x16: pixel row inside a 16-deep k-step (+4: second read); 16x16x32: inside a 32-deep step (+16: second read)
+  const int rowl = M16 ? 4 * g16 + lq : 8 * (g16 >> 1) + lq;
+  const int inseg = M16 ? (4 * lp) * 2 : (16 * (g16 & 1) + 4 * lp) * 2;      // byte inside a 64-B segment (16x16x32: a 32-B unit)
   // dy fragment offsets inside a stage (pixel rows are chunk-local: key is lane-constant)
   uint32_t a_rd[2];
 #pragma unroll
@@ -277,6 +313,23 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
       bbase[s] = lds0 + r * 128 + ((wh ^ ((r >> 1) & 1)) << 6) + inseg;      // (r + 16 ks + 4) >> 1 has the parity of r >> 1
     }
   };
+
+  // 16x16x32: per-lane fragment offsets, relative to the dy stage / to the window's first ring row (a multiple of 8 rows, so the
+  // swizzle bits of a row are those of its offset); the chunk's part is a scalar added at the read
+  uint32_t aoff[M16 ? 4 : 1], boff[M16 ? 6 : 1];
+  if constexpr (M16) {
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int seg = wk * 2 + (i4 >> 1), sub = i4 & 1;
+      const int key = KH == 2 ? (lq & 3) : ((lq >> 1) & 1);
+      aoff[i4] = lds0 + XBYTES + (wp * 64 + rowl) * DROW + ((seg ^ key) << 6) + ((sub ^ (g16 & 1)) << 5) + inseg;
+    }
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int r = rowoff[n >> 1], sub = n & 1;
+      boff[n] = lds0 + r * 128 + ((wh ^ ((r >> 1) & 1)) << 6) + ((sub ^ ((r >> 2) & 1)) << 5) + inseg;
+    }
+  }
 
   // ---- prologue: window of the first chunk + its dy, all of chunk c0 + 1 (every wave takes part, offsets by division),
   //      and the DMA waves' table values of chunk c0 + 2 (fired in the first iteration)
@@ -318,8 +371,139 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   const unsigned long long pr_w0 = PROBE ? (wall_clock64() & 0xFFFFFFFFull) : 0ull;
 
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  s16x4 ra[2][2][2], rb[2][3][2];      // [buffer][tile][half]: the fragments of k-step ks live in buffer ks & 1
 #define WGW_FRAG(v) __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector((v)[0], (v)[1], 0, 1, 2, 3, 4, 5, 6, 7))
+  if constexpr (M16) {
+    s16x4 A16[2][4][2], B16[4][2];      // dy sub-tiles [buffer = step parity][sub-tile][half]; x sub-tile ring [slot][half]
+    // (aoff / boff hold the CURRENT chunk's fragment addresses; they move to the next chunk by a scalar difference -- ten VALU
+    //  instructions per chunk: at 16 cycles per MFMA the matrix instructions alone take half of the SIMD's issue slots, and an
+    //  address add per read pair showed as +10 % cycles per chunk)
+#define WGW_RA16(buf, i4, KN) do { A16[buf][i4][0] = wgw_read_tr_o<(KN) * 32 * DROW>(aoff[i4]); A16[buf][i4][1] = wgw_read_tr_o<(KN) * 32 * DROW + 16 * DROW>(aoff[i4]); } while (0)
+#define WGW_RB16(slot, n, KN) do { B16[slot][0] = wgw_read_tr_o<(KN) * 4096>(boff[n]); B16[slot][1] = wgw_read_tr_o<(KN) * 4096 + 2048>(boff[n]); } while (0)
+#define WGW_MF16(n, i4) acc16[i4][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WGW_FRAG(A16[cur][i4]), WGW_FRAG(B16[WGW_SL(n)]), acc16[i4][n], 0, 0, 0)
+#define WGW_MF16_REST(n) do { WGW_MF16(n, 1); WGW_MF16(n, 2); WGW_MF16(n, 3); } while (0)
+    // one 32-pixel step KS of a chunk: six groups of four MFMAs (x sub-tile n against the four dy sub-tiles).  Behind the first
+    // MFMA of group n go out the reads of the NEXT step's dy sub-tile n (n < 4) and of the x sub-tile three groups ahead (ring of
+    // four slots; two groups ahead left the waves waiting on the LDS three times as long as the 32x32x16 loop:
+    // SQ_WAIT_INST_LDS 16.5 M against 5.2 M wave-cycles per launch).  Reads return in order: counted waits.
+    // In the chunk's second step every dy read and the reads of x sub-tiles 0..2 belong to the NEXT chunk: `d_dy` / `d_x` (scalar
+    // address differences) move aoff[0..3], boff[0..2] at its top and boff[3..5] behind their last read.
+    auto kstep16 = [&](auto KS_, auto&& slot0, auto&& slot3, int d_dy, int d_x) {
+      constexpr int KS = decltype(KS_)::value;
+      constexpr int cur = KS, nxt = KS ^ 1, KN = KS ^ 1;
+#define WGW_SL(n) ((6 * KS + (n)) & 3)
+#define WGW_SLN(n) ((6 * KS + (n) + 3) & 3)
+      if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(3 - 2 * KS);
+      if constexpr (KS == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aoff[i] += d_dy;
+        boff[0] += d_x; boff[1] += d_x; boff[2] += d_x;
+      }
+      wgw_wait_lgkm<4>(A16[cur], B16[WGW_SL(0)][0], B16[WGW_SL(0)][1]);          // younger: x 1, x 2
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_RA16(nxt, 0, KN);
+      WGW_RB16(WGW_SLN(0), 3, KS);
+      slot0();
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16_REST(0);
+      __builtin_amdgcn_sched_barrier(0);
+      wgw_wait_lgkm<6>(B16[WGW_SL(1)][0], B16[WGW_SL(1)][1]);                    // younger: x 2, dy' 0, x 3
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_RA16(nxt, 1, KN);
+      WGW_RB16(WGW_SLN(1), 4, KS);
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16_REST(1);
+      __builtin_amdgcn_sched_barrier(0);
+      wgw_wait_lgkm<8>(B16[WGW_SL(2)][0], B16[WGW_SL(2)][1]);                    // younger: dy' 0, x 3, dy' 1, x 4
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16(2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_RA16(nxt, 2, KN);
+      WGW_RB16(WGW_SLN(2), 5, KS);
+      if constexpr (KS == 1) { boff[3] += d_x; boff[4] += d_x; boff[5] += d_x; }
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16_REST(2);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(2 - 2 * KS);
+      wgw_wait_lgkm<8>(B16[WGW_SL(3)][0], B16[WGW_SL(3)][1]);                    // younger: dy' 1, x 4, dy' 2, x 5
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16(3, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_RA16(nxt, 3, KN);
+      WGW_RB16(WGW_SLN(3), 0, KN);
+      slot3();
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16_REST(3);
+      __builtin_amdgcn_sched_barrier(0);
+      wgw_wait_lgkm<8>(B16[WGW_SL(4)][0], B16[WGW_SL(4)][1]);                    // younger: dy' 2, x 5, dy' 3, x' 0
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16(4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_RB16(WGW_SLN(4), 1, KN);
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16_REST(4);
+      __builtin_amdgcn_sched_barrier(0);
+      wgw_wait_lgkm<6>(B16[WGW_SL(5)][0], B16[WGW_SL(5)][1]);                    // younger: dy' 3, x' 0, x' 1
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16(5, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_RB16(WGW_SLN(5), 2, KN);
+      __builtin_amdgcn_sched_barrier(0);
+      WGW_MF16_REST(5);
+      __builtin_amdgcn_sched_barrier(0);
+#undef WGW_SLN
+#undef WGW_SL
+    };
+    auto ds_of = [&](int ci) -> uint32_t { return (uint32_t)((ci % NST) * DSTAGE); };
+    auto cb_of = [&](int ci) -> uint32_t { return (uint32_t)(ring(ci * CHUNK - p.halo8) * 128); };
+    {
+      const uint32_t d0 = ds_of(c0), w0 = cb_of(c0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) aoff[i] += d0;
+#pragma unroll
+      for (int n = 0; n < 6; ++n) boff[n] += w0;
+      WGW_RA16(0, 0, 0); WGW_RA16(0, 1, 0); WGW_RA16(0, 2, 0); WGW_RA16(0, 3, 0);
+      WGW_RB16(0, 0, 0); WGW_RB16(1, 1, 0); WGW_RB16(2, 2, 0);
+    }
+    // (loop invariant, DMA and table handling: as in the 32x32x16 loop below)
+    for (int ci = c0; ci < c1; ++ci) {
+      const unsigned long long q0 = WGW_NOW();
+      wgw_wait_vmcnt<0>();
+      const unsigned long long q1 = WGW_NOW();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned long long q2 = WGW_NOW();
+      pr_wait += q1 - q0;
+      pr_bar += q2 - q1;
+      const bool more2 = ci + 2 < c1 && !(p.dbg & 8);
+      const bool more3 = ci + 3 < c1 && !(p.dbg & 4);
+      auto dma_burst = [&]() {
+        if (more2) { fire_piece(WgwInt<0>{}, ci + 2); fire_piece(WgwInt<1>{}, ci + 2); fire_piece(WgwInt<2>{}, ci + 2); fire_piece(WgwInt<3>{}, ci + 2); }
+        if (more3) { load_piece(WgwInt<0>{}, ci + 3); load_piece(WgwInt<1>{}, ci + 3); load_piece(WgwInt<2>{}, ci + 3); load_piece(WgwInt<3>{}, ci + 3); }
+      };
+      const int d_dy = (int)ds_of(ci + 1) - (int)ds_of(ci), d_x = (int)cb_of(ci + 1) - (int)cb_of(ci);
+      kstep16(WgwInt<0>{},
+              [&]() {
+                convert_pieces();
+#pragma unroll
+                for (int j = 0; j < NP; ++j) asm volatile("" : "+v"(tc[j]));
+                if (dma_ks == 0) dma_burst();
+              },
+              [&]() { if (dma_ks == 1) dma_burst(); }, 0, 0);
+      // (beyond the last chunk the reads of the second step are dummies that keep the wait counts uniform: any address inside
+      //  the allocation is fine)
+      kstep16(WgwInt<1>{}, [&]() {}, [&]() {}, d_dy, d_x);
+      pr_comp += WGW_NOW() - q2;
+    }
+#undef WGW_MF16_REST
+#undef WGW_MF16
+#undef WGW_RB16
+#undef WGW_RA16
+  } else {
+  s16x4 ra[2][2][2], rb[2][3][2];      // [buffer][tile][half]: the fragments of k-step ks live in buffer ks & 1
 #define WGW_RA(buf, i, KN) do { ra[buf][i][0] = wgw_read_tr_o<(KN) * 16 * DROW>(abase[i]); ra[buf][i][1] = wgw_read_tr_o<(KN) * 16 * DROW + 4 * DROW>(abase[i]); } while (0)
 #define WGW_RB(buf, s, KN) do { rb[buf][s][0] = wgw_read_tr_o<(KN) * 2048>(bbase[s]); rb[buf][s][1] = wgw_read_tr_o<(KN) * 2048 + 512>(bbase[s]); } while (0)
 #define WGW_MFMA(i, s) acc[i][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WGW_FRAG(ra[cur][i]), WGW_FRAG(rb[cur][s]), acc[i][s], 0, 0, 0)
@@ -393,7 +577,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
       //  instructions just issued)
       convert_pieces();
 #pragma unroll
-      for (int j = 0; j < NP; ++j) asm volatile("" : "+v"(t[j]));
+      for (int j = 0; j < NP; ++j) asm volatile("" : "+v"(tc[j]));
       if (dma_ks == 0) dma_burst();
     });
     kstep(WgwInt<1>{}, [&]() { if (dma_ks == 1) dma_burst(); });
@@ -404,6 +588,7 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
     __builtin_amdgcn_sched_barrier(0);
     kstep(WgwInt<3>{}, [&]() {});
     pr_comp += WGW_NOW() - q2;
+  }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the dummy reads of the last k-step
 #undef WGW_MFMA
@@ -424,7 +609,8 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
 #undef WGW_NOW
 
   if (p.dbg & 1) {      // timing experiment: no epilogue (one conditional store keeps the accumulators alive)
-    if (acc[0][0][0] + acc[1][2][5] == 12345.f) p.dw[0] = 1.f;
+    if constexpr (M16) { if (acc16[0][0][0] + acc16[3][5][2] == 12345.f) p.dw[0] = 1.f; }
+    else { if (acc[0][0][0] + acc[1][2][5] == 12345.f) p.dw[0] = 1.f; }
     return;
   }
   if (PS == 2) {
@@ -435,17 +621,35 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
     for (int i = 0; i < 2; ++i) {
       __syncthreads();
       if (wp == 1) {
+        if constexpr (M16) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n = 0; n < 6; ++n)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) red[(role * 48 + (h * 6 + n) * 4 + e) * 64 + lane] = acc16[2 * i + h][n][e];
+        } else {
 #pragma unroll
         for (int s2 = 0; s2 < 3; ++s2)
 #pragma unroll
           for (int e = 0; e < 16; ++e) red[((role * 3 + s2) * 16 + e) * 64 + lane] = acc[i][s2][e];
+        }
       }
       __syncthreads();
       if (wp == 0) {
+        if constexpr (M16) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n = 0; n < 6; ++n)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc16[2 * i + h][n][e] += red[(role * 48 + (h * 6 + n) * 4 + e) * 64 + lane];
+        } else {
 #pragma unroll
         for (int s2 = 0; s2 < 3; ++s2)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][s2][e] += red[((role * 3 + s2) * 16 + e) * 64 + lane];
+        }
       }
     }
     if (wp == 1) return;
@@ -455,6 +659,22 @@ __global__ __launch_bounds__(384 * KH * PS) void conv_wgrad_win_kernel(const Wgw
   // ~6 TB/s, and every launch emits 256 CUs x 295 KB of accumulators -- else fp32 atomics into [K][(r,s)][C]
   const int ln = lane & 31, lh = lane >> 5;
   float* const slice = p.part ? p.part + (size_t)split * p.K * p.Ng : nullptr;
+  if constexpr (M16) {
+    // 16 x 16 sub-tiles: lane -> column lane % 16, rows 4 (lane / 16) + e
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+      for (int n6 = 0; n6 < 6; ++n6) {
+        const int n = (wr * 3 + (n6 >> 1)) * p.C + cb * 64 + wh * 32 + (n6 & 1) * 16 + (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = kt * 64 * KH + wk * 64 + i4 * 16 + 4 * (lane >> 4) + e;
+          if (slice) slice[(size_t)k * p.Ng + n] = acc16[i4][n6][e];
+          else atomicAdd(p.dw + (size_t)k * p.Ng + n, acc16[i4][n6][e]);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -586,21 +806,23 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   const dim3 grid(nsplit * tiles);
   // x ring + its mirror + three dy stages: 136 KB (K % 128 == 0), 144 KB (K = 64 on twelve waves), 112 KB (six waves)
   const size_t lds = (size_t)(512 + 64 * PS + 128) * 128 + 3 * (size_t)(64 * PS) * 128 * KH;
-#define MPR_WGW(KH_, PS_, PRIO_, PROBE_)                                                                               \
+#define MPR_WGW(KH_, PS_, PRIO_, PROBE_, M16_)                                                                         \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
-      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<KH_, PS_, PRIO_, PROBE_>,                                 \
+      hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<KH_, PS_, PRIO_, PROBE_, M16_>,                           \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                     \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
-    conv_wgrad_win_kernel<KH_, PS_, PRIO_, PROBE_><<<grid, 384 * KH_ * PS_, lds, st>>>(p);                             \
+    conv_wgrad_win_kernel<KH_, PS_, PRIO_, PROBE_, M16_><<<grid, 384 * KH_ * PS_, lds, st>>>(p);                       \
   } while (0)
-#define MPR_WGW2(KH_, PS_)                                                                                             \
+#define MPR_WGW3(KH_, PS_, M16_)                                                                                       \
   do {                                                                                                                 \
-    if (p.probe) { if (prio) MPR_WGW(KH_, PS_, 1, true); else MPR_WGW(KH_, PS_, 0, true); }                            \
-    else { if (prio) MPR_WGW(KH_, PS_, 1, false); else MPR_WGW(KH_, PS_, 0, false); }                                  \
+    if (p.probe) { if (prio) MPR_WGW(KH_, PS_, 1, true, M16_); else MPR_WGW(KH_, PS_, 0, true, M16_); }                \
+    else { if (prio) MPR_WGW(KH_, PS_, 1, false, M16_); else MPR_WGW(KH_, PS_, 0, false, M16_); }                      \
   } while (0)
+  // (dbg bit 6: the 32x32x16 form, comparisons)
+#define MPR_WGW2(KH_, PS_) do { if (p.dbg & 64) MPR_WGW3(KH_, PS_, false); else MPR_WGW3(KH_, PS_, true); } while (0)
   // s_setprio by k-step (a wave that is behind outranks one that is ahead): 3125 -> 2750 cycles per chunk at K % 128 == 0,
   // 139 -> 134 us per layer1 launch; dbg bit 4 switches it off (comparisons)
   const bool prio = !(p.dbg & 16);
@@ -608,6 +830,7 @@ int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W
   else if (KH == 2) MPR_WGW2(2, 1);
   else MPR_WGW2(1, 1);
 #undef MPR_WGW2
+#undef MPR_WGW3
 #undef MPR_WGW
   MPR_LAUNCH_CHECK("conv_wgrad_win_kernel");
   if (p.part) {
