@@ -70,7 +70,12 @@ def test_oracle_efficientnet_equals_a_torch_nn_restatement():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,H,W,C,k,stride', [(2, 17, 13, 16, 3, 1), (3, 16, 16, 24, 5, 2), (1, 9, 20, 96, 3, 2),
-                                              (2, 7, 7, 40, 5, 1)])
+                                              (2, 7, 7, 40, 5, 1),
+                                              # the register-tiled kernels at EfficientNet-B0's widths: partial strips (7, 14 and
+                                              # odd widths), channel-group counts that are not powers of two (18, 84, 144)
+                                              (2, 14, 14, 480, 3, 1), (3, 7, 7, 1152, 5, 1), (2, 28, 28, 144, 5, 2),
+                                              (2, 15, 17, 672, 5, 2), (2, 56, 56, 32, 3, 1), (5, 14, 14, 672, 5, 1),
+                                              (2, 29, 31, 240, 3, 2)])
 def test_depthwise_conv_kernels(B, H, W, C, k, stride):
     from multimodal_plankton_recognition_amd import efficientnet as E
     from multimodal_plankton_recognition_amd.ops import ConvGeom
