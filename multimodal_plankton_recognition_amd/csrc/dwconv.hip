@@ -400,19 +400,31 @@ __global__ __launch_bounds__(256) void se_sum_kernel(const uint4* __restrict__ x
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  if (cg < G) {
-    for (int l = rl; l < L; l += nl) {
-      float a[8];
-      const size_t o = ((size_t)b * L + l) * G + cg;
-      unpack8(x[o], a);
-      if (MUL) {
-        float d[8];
-        unpack8(dy[o], d);
+  if (cg < G && rl < nl) {
+    // (U pixels per iteration, their loads first: one block per image leaves 4 waves per CU, each needs loads in flight)
+    constexpr int U = MUL ? 4 : 8;
+    for (int l = rl; l < L; l += nl * U) {
+      uint4 xv[U], dv[MUL ? U : 1];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(a[e], d[e], acc[e]);
-      } else {
+      for (int u = 0; u < U; ++u) {
+        const int lu = l + u * nl;
+        const size_t o = ((size_t)b * L + (lu < L ? lu : l)) * G + cg;
+        xv[u] = lu < L ? x[o] : make_uint4(0u, 0u, 0u, 0u);
+        if (MUL) dv[u] = dy[o];
+      }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += a[e];
+      for (int u = 0; u < U; ++u) {
+        float a[8];
+        unpack8(xv[u], a);
+        if (MUL) {
+          float d[8];
+          unpack8(dv[u], d);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = fmaf(a[e], d[e], acc[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += a[e];
+        }
       }
     }
   }
@@ -433,6 +445,12 @@ static inline int se_gp(int C) {
   int gp = 1;
   while (gp < C / 8 && gp < 256) gp <<= 1;
   return gp;
+}
+// channel groups per block of the per-image sums: G / ceil(G / 64) (no power of two needed: a block of 256 at G = 144 left
+// 44 % of its threads without a channel group and ONE row lane for the rest)
+static inline int se_gp_sum(int C) {
+  const int G = C / 8;
+  return ceil_div(G, ceil_div(G, 64));
 }
 
 static inline unsigned dw_grid(long long n) {
@@ -550,7 +568,7 @@ int mpr_se_scale(const void* x, const float* gate, void* y, int B, int L, int C,
 
 int mpr_se_dgate(const void* x, const void* dy, float* dgate, int B, int L, int C, void* stream) {
   MPR_REQUIRE(x && dy && dgate && B > 0 && B <= 65535 && L > 0 && C > 0 && C % 8 == 0, "mpr_se_dgate: bad arguments");
-  const int gp = se_gp(C);
+  const int gp = se_gp_sum(C);
   se_sum_kernel<true><<<dim3(ceil_div(C / 8, gp), B), 256, 0, (hipStream_t)stream>>>((const uint4*)x, (const uint4*)dy, dgate, L, C,
                                                                                      gp, 1.f);
   MPR_LAUNCH_CHECK("se_sum_kernel");
@@ -559,7 +577,7 @@ int mpr_se_dgate(const void* x, const void* dy, float* dgate, int B, int L, int 
 
 int mpr_se_pool(const void* x, float* pooled, int B, int L, int C, void* stream) {
   MPR_REQUIRE(x && pooled && B > 0 && B <= 65535 && L > 0 && C > 0 && C % 8 == 0, "mpr_se_pool: bad arguments");
-  const int gp = se_gp(C);
+  const int gp = se_gp_sum(C);
   se_sum_kernel<false><<<dim3(ceil_div(C / 8, gp), B), 256, 0, (hipStream_t)stream>>>((const uint4*)x, nullptr, pooled, L, C, gp,
                                                                                       1.f / (float)L);
   MPR_LAUNCH_CHECK("se_sum_kernel");
