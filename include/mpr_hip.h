@@ -429,6 +429,18 @@ int mpr_se_scale(const void* x /* [B][L][C] bf16 */, const float* gate /* [B][C]
                  void* stream);
 int mpr_se_dgate(const void* x, const void* dy, float* dgate /* [B][C] = sum_l dy * x */, int B, int L, int C, void* stream);
 int mpr_se_pool(const void* x, float* pooled /* [B][C] = mean_l x */, int B, int L, int C, void* stream);
+/* the SE bottleneck on the pooled map in one launch forward / two backward (se_mlp.hip; rd <= mpr_se_mlp_max_rd()):
+ *   z1 = pooled W1^T + b1, r = silu(z1), gate = sigmoid(r W2^T + b2)      w1: [rd][C], w2: [C][rd] (the 1x1 conv filters)
+ * backward from dgate = d loss / d gate: dz2, dz1 (scratch, [B][C] / [B][rd]), dpooled = dpooled_scale * dz1 W1, and the
+ * parameter gradients ACCUMULATED into dw1 / db1 / dw2 / db2 (fp32 atomics: zero them first) */
+int mpr_se_mlp_max_rd(void);
+int mpr_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* z1, float* r,
+                   float* gate, int B, int C, int rd, void* stream);
+int mpr_se_mlp_bwd(const float* dgate, const float* gate, const float* z1, const float* r, const float* pooled, const float* w1,
+                   const float* w2, float* dz2, float* dz1, float* dpooled, float* dw1, float* db1, float* dw2, float* db2,
+                   float dpooled_scale, int B, int C, int rd, void* stream);
+/* y = x * gate[b][c] + add[b][c] (the gated map's data gradient with the pooled path's per-image constant folded in) */
+int mpr_se_scale_add(const void* x, const float* gate, const float* add, void* y, int B, int L, int C, void* stream);
 
 /* ---- input pipeline, the per-step random part on pre-decoded batches (src/data.py:73-91,124-141,198-204): the random
  *      decisions (crop offsets, flips) are INPUTS (int32 / byte vectors of length B) */

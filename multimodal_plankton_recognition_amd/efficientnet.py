@@ -145,10 +145,18 @@ class SqueezeExciteFn(torch.autograd.Function):
         rd = w1.shape[0]
         pooled = torch.empty(B, C, dtype=F32, device=x.device)
         N.call('mpr_se_pool', x, pooled, B, H * W, C)                                 # squeeze: mean over pixels
-        z1 = ops.gemm(pooled, w1.detach().view(rd, C), trans_b=True)                  # pre-activation (bias added in act)
-        r = _act32(z1, b1, _SILU)
-        z2 = ops.gemm(r, w2.detach().view(C, rd), trans_b=True)
-        gate = _act32(z2, b2, _SIGMOID)
+        ctx.fused = rd <= N.query('mpr_se_mlp_max_rd')
+        if ctx.fused:                                                                  # the bottleneck in one launch
+            z1 = torch.empty(B, rd, dtype=F32, device=x.device)
+            r = torch.empty_like(z1)
+            gate = torch.empty(B, C, dtype=F32, device=x.device)
+            z2 = gate
+            N.call('mpr_se_mlp_fwd', pooled, w1.detach(), b1.detach(), w2.detach(), b2.detach(), z1, r, gate, B, C, rd)
+        else:
+            z1 = ops.gemm(pooled, w1.detach().view(rd, C), trans_b=True)              # pre-activation (bias added in act)
+            r = _act32(z1, b1, _SILU)
+            z2 = ops.gemm(r, w2.detach().view(C, rd), trans_b=True)
+            gate = _act32(z2, b2, _SIGMOID)
         y = torch.empty_like(x)
         N.call('mpr_se_scale', x, gate, y, B, H * W, C)
         ctx.save_for_backward(x, pooled, z1, r, z2, gate, w1, b1, w2, b2)
@@ -164,6 +172,18 @@ class SqueezeExciteFn(torch.autograd.Function):
         dgate = torch.empty(B, C, dtype=F32, device=dev)
         N.call('mpr_se_dgate', x, dy, dgate, B, H * W, C)
         dx = torch.empty_like(x)
+        if ctx.fused:
+            # one buffer for the four parameter gradients (accumulated by atomics: zeroed in one launch) and the scratch
+            n1, n2 = rd * C, C * rd
+            buf = torch.zeros(n1 + rd + n2 + C, dtype=F32, device=dev)
+            dw1, db1, dw2, db2 = buf[:n1], buf[n1:n1 + rd], buf[n1 + rd:n1 + rd + n2], buf[n1 + rd + n2:]
+            scr = torch.empty(2 * B * C + B * rd, dtype=F32, device=dev)
+            dz2, dpooled, dz1 = scr[:B * C], scr[B * C:2 * B * C], scr[2 * B * C:]
+            N.call('mpr_se_mlp_bwd', dgate, gate, z1, r, pooled, w1.detach(), w2.detach(), dz2, dz1, dpooled, dw1, db1, dw2, db2,
+                   1.0 / (H * W), B, C, rd)
+            # direct path dy * gate and the gate path through the mean (a per-image constant) in one pass
+            N.call('mpr_se_scale_add', dy, gate, dpooled, dx, B, H * W, C)
+            return dx, dw1.view(w1.shape), db1, dw2.view(w2.shape), db2
         N.call('mpr_se_scale', dy, gate, dx, B, H * W, C)                             # direct path: dy * gate
         dz2 = _act32_bwd(dgate, z2, b2, _SIGMOID)
         ones = torch.ones(B, 1, dtype=F32, device=dev)

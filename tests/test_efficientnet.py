@@ -98,9 +98,11 @@ def test_depthwise_conv_kernels(B, H, W, C, k, stride):
 
 
 @pytest.mark.gpu
-def test_squeeze_excite_and_silu_functions():
+@pytest.mark.parametrize('B,C,rd', [(3, 48, 12), (70, 1152, 48), (5, 24, 6), (3, 48, 72)])
+def test_squeeze_excite_and_silu_functions(B, C, rd):
+    """rd <= 64: the bottleneck in one launch forward / two backward (csrc/se_mlp.hip); wider: the GEMM path."""
     from multimodal_plankton_recognition_amd import efficientnet as E
-    B, H, W, C, rd = 3, 6, 5, 48, 12
+    H, W = 6, 5
     x = rnd(B, C, H, W, seed=1).to(BF).float()
     ps = [rnd(rd, C, 1, 1, seed=2, scale=0.2), rnd(rd, seed=3, scale=0.2), rnd(C, rd, 1, 1, seed=4, scale=0.2), rnd(C, seed=5, scale=0.2)]
     xr = x.clone().requires_grad_(True)
