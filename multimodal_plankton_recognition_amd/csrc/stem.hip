@@ -152,6 +152,68 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
 }
 
+// One input channel, 3 x 3 filter (EfficientNet's stem on grayscale plankton images; round 3): the generic kernel above gives a
+// thread ONE tap -- nine of its 64 tap lanes work, every lane re-loads the same gradient group -- and took 1 ms at batch 256.
+// Here a thread owns 8 output channels x ALL nine taps (72 accumulators) and walks pixels: lanes of a wave = cgn channel groups x
+// 64 / cgn consecutive pixels (the gradient rows of a wave are one contiguous run, the nine x values of a pixel three short
+// runs); lanes of equal channel group meet by wave shuffles, the block's waves in LDS, blocks by fp32 atomics.
+__global__ __launch_bounds__(256) void stem_wgrad_c1k3_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                              float* __restrict__ dw, StemGeom g, int pix_per_block) {
+  __shared__ float red[4][64][9];
+  const int cgn = g.K >> 3;                    // power of two, <= 64 (host)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = lane % cgn, pl = tid / cgn, npl = 256 / cgn;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+  const int npix = g.B * g.P * g.Q;
+  const int p0 = blockIdx.x * pix_per_block;
+  int p1 = p0 + pix_per_block;
+  if (p1 > npix) p1 = npix;
+  for (int pix = p0 + pl; pix < p1; pix += npl) {
+    const int q = pix % g.Q, t0 = pix / g.Q;
+    const int p = t0 % g.P, b = t0 / g.P;
+    const uint4 dv = reinterpret_cast<const uint4*>(dy)[(size_t)pix * cgn + cg];
+    float xv[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) {
+        const int ih = p * g.sh - g.ph + r, iw = q * g.sw - g.pw + s2;
+        const bool ok = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        xv[r * 3 + s2] = ok ? x[((size_t)b * g.H + ih) * g.W + iw] : 0.f;
+      }
+    float d[8];
+    unpack8(dv, d);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(xv[t], d[e], acc[t][e]);
+  }
+  // lanes of equal channel group within the wave
+  for (int off = cgn; off < 64; off <<= 1)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[t][e] += __shfl_xor(acc[t][e], off);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __syncthreads();
+    if (lane < cgn) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) red[wave][lane][t] = acc[t][e];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < cgn) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        atomicAdd(dw + (size_t)(cg * 8 + e) * 9 + t, (red[0][lane][t] + red[1][lane][t]) + (red[2][lane][t] + red[3][lane][t]));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // ResNet stem (1 input channel, 7x7, stride 2, pad 3) as a space-to-depth problem: the stride-2 7x7 filter on
 // 1 channel equals a stride-1 4x4 filter on the 4 phase channels of the 2x2-decimated image (filter padded to
@@ -270,6 +332,14 @@ int mpr_stem_wgrad(const float* x, const void* dy, float* dw, int accumulate, in
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate) MPR_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * g.taps, st));
   const int npix = B * g.P * g.Q;
+  const int cgn = K / 8;
+  if (Cin == 1 && R == 3 && S == 3 && cgn <= 64 && (cgn & (cgn - 1)) == 0) {
+    int ppb1 = ceil_div(npix, 2048);
+    if (ppb1 < 256) ppb1 = 256;
+    stem_wgrad_c1k3_kernel<<<ceil_div(npix, ppb1), 256, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb1);
+    MPR_LAUNCH_CHECK("stem_wgrad_c1k3_kernel");
+    return MPR_OK;
+  }
   int grid = 8192;
   int ppb = ceil_div(npix, grid);
   if (ppb < 16) ppb = 16;

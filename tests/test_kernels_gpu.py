@@ -156,11 +156,12 @@ def test_conv_large_rows_many_tiles(igemm_path):
     np.testing.assert_allclose(dw.cpu().numpy(), wg.grad.numpy(), rtol=3e-3, atol=3e-3 * float(wg.grad.abs().max()))
 
 
-@pytest.mark.parametrize('dims', [2, 1])
+@pytest.mark.parametrize('dims', [2, 1, 3])
 def test_stem_fwd_and_wgrad(dims):
     ops = _ops()
-    if dims == 2:
-        B, H, W, Cin, K, R, st, pad = 3, 30, 26, 1, 64, 7, 2, 3
+    if dims in (2, 3):
+        # (3: EfficientNet's stem -- one channel, 3 x 3, stride 2: the all-taps-per-thread weight gradient of stem.hip)
+        B, H, W, Cin, K, R, st, pad = (3, 30, 26, 1, 64, 7, 2, 3) if dims == 2 else (5, 37, 30, 1, 32, 3, 2, 1)
         x = rnd(B, Cin, H, W, seed=11)
         w = rnd(K, Cin, R, R, seed=12, scale=0.1)
         g = ops.ConvGeom((K, Cin, R, R), st, pad)
@@ -181,7 +182,7 @@ def test_stem_fwd_and_wgrad(dims):
     np.testing.assert_allclose(stats.cpu().sum(0)[0].numpy(), yr.sum(0).numpy(), rtol=1e-3, atol=1e-2)
     dy = bf(rnd(*ref.shape, seed=15)).float()
     wg = w.clone().requires_grad_(True)
-    (F.conv2d(x, wg, None, st, pad) if dims == 2 else F.conv1d(x, wg, None, st, pad)).backward(dy)
+    (F.conv2d(x, wg, None, st, pad) if dims != 1 else F.conv1d(x, wg, None, st, pad)).backward(dy)
     dw = ops.stem_wgrad(xin, bf(to_cl(dy)).to(DEV), g, tuple(w.shape))
     np.testing.assert_allclose(dw.cpu().numpy(), wg.grad.numpy(), rtol=1e-3, atol=1e-3 * float(wg.grad.abs().max()))
 
