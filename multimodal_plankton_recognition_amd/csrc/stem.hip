@@ -340,9 +340,11 @@ int mpr_stem_wgrad(const float* x, const void* dy, float* dw, int accumulate, in
     MPR_LAUNCH_CHECK("stem_wgrad_c1k3_kernel");
     return MPR_OK;
   }
+  // (every block ends in K x taps fp32 atomics on the SAME addresses: 2048 blocks of 16 pixels on the profile stem's 32 K
+  //  positions spent most of their 161 us queueing there)
   int grid = 8192;
   int ppb = ceil_div(npix, grid);
-  if (ppb < 16) ppb = 16;
+  if (ppb < 64) ppb = 64;
   grid = ceil_div(npix, ppb);
   const int maxt = ceil_div(g.taps, ntl);
   if (maxt == 1) stem_wgrad_kernel<1><<<grid, block, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb);

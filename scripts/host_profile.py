@@ -4,12 +4,12 @@ sys.path.insert(0, '.')
 import bench
 from multimodal_plankton_recognition_amd.model import MultiModel
 dev = torch.device('cuda', 0)
-card = yaml.safe_load(open(bench.CARD))
+card = yaml.safe_load(open(sys.argv[2] if len(sys.argv) > 2 else bench.CARD))
 torch.manual_seed(0)
 model = MultiModel(card['dim_embedding'], card['image_encoder_args'], card['profile_encoder_args'],
                    card['coordination_args'], card['optim_args']).to(dev).train()
 opt = model.configure_optimizers()
-batch = bench.synthetic_batch(card['bs'], card['target_size'], dev, 1234)
+batch = bench.synthetic_batch(int(sys.argv[3]) if len(sys.argv) > 3 else card["bs"], card['target_size'], dev, 1234)
 batch['buckets'] = card['buckets']
 def one_step():
     opt.zero_grad()
