@@ -12,7 +12,7 @@
  *   - return value: 0 = ok, 1 = invalid argument, 2 = HIP runtime error; mpr_last_error() gives the
  *     message for the calling thread.  Nothing aborts.
  *   - "stat rows": train-mode BatchNorm statistics are partial sums [rows][2][C] (sum, sum of squares).  By default
- *     the producers ADD into a small fixed number of zeroed slice rows (fp32 atomics, mpr_conv_set_stat_slices: 8) that
+ *     the producers ADD into a small fixed number of zeroed slice rows (fp32 atomics, mpr_conv_set_stat_slices: 4) that
  *     the consuming kernel finalizes itself (mpr_bn_apply_fin, mpr_bn_bwd_apply_fin, mpr_stemf_pool); with slices off they
  *     write one row per workgroup (bitwise reproducible; the *_stat_rows / mpr_bn_reduce_rows functions give the count)
  *     for mpr_bn_reduce_partials / mpr_bn_finalize_stats.

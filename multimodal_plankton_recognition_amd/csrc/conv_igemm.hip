@@ -844,7 +844,7 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
 // BatchNorm partial sums of the forward convolutions: n > 0 = every tile adds (fp32 atomics) into one of n slice rows that
 // the launcher zeroes -- the consumer finalizes from the n rows directly and the pre-reduction launch between a convolution and
 // its BatchNorm disappears; 0 = one row per tile (bitwise reproducible sums).  Returns the previous setting.
-static int g_stat_slices = 8;
+static int g_stat_slices = 4;      // (= ops.FIN_SLICES)
 int mpr_conv_stat_slices() { return g_stat_slices; }
 // one-shot promise of the caller that the slice rows handed to the NEXT mpr_conv_fwd are already zero (a per-step arena
 // zeroed in one go): the launcher then skips its own memset -- 40 fill launches of ~5 us per C3 step otherwise

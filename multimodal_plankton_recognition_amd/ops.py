@@ -591,7 +591,9 @@ def _prereduce(parts, nsplit=64, limit=512):
 # BatchNorm finalize folded into the consuming apply kernel (mpr_bn_apply_fin / mpr_bn_bwd_apply_fin): the partial sums
 # are pre-reduced to FIN_SLICES rows and every workgroup of the apply kernel finishes them itself.
 FIN_IN_CONSUMER = os.environ.get('MPR_FIN_IN_CONSUMER', '1') != '0'
-FIN_SLICES = 8
+# (4 = the library's default; round 3, one step in ms with 1 / 2 / 4 / 8 / 16 / 32 / 64 slice rows: 9.56 / 9.33 / 9.33 / 9.40 /
+#  9.57 / 9.79 / 10.3 -- every workgroup of an apply pass sums the rows itself; the contention of the atomics does not show)
+FIN_SLICES = int(os.environ.get('MPR_FIN_SLICES', '4'))
 # short partial lists of narrow layers (rows x C floats per sum <= this) are handed to the consumer as they are: the
 # pre-reduction launch costs more than every apply workgroup summing <= 16 KB itself (the profile branch's 1-D layers:
 # 14..112 partial rows of 256..32 channels -- ~45 fewer launches per step on that latency-bound stream)
@@ -602,6 +604,8 @@ BWD_ATOMIC_SLICES = os.environ.get('MPR_BWD_ATOMIC_SLICES', '1') != '0'
 # or more BatchNorm calls per step than slots) the launcher zeroes a fresh buffer itself.
 SLICE_ARENA = os.environ.get('MPR_SLICE_ARENA', '1') != '0'
 _SLICE_SLOTS, _SLICE_FLOATS = 512, FIN_SLICES * 2 * 512
+if 'MPR_FIN_SLICES' in os.environ:      # experiment only: the forward kernels' slice count is a process-wide library setting
+    N.query('mpr_conv_set_stat_slices', FIN_SLICES)
 _slice_arena = {}          # device -> [tensor [slots][floats], next free slot]
 
 
