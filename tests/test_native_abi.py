@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_size_queries_match_documented_tiling():
     rows = lambda *a: _native.query('mpr_conv_fwd_stat_rows', *a)
-    # default: every tile adds into one of 8 slice rows (no pre-reduction launch before the BatchNorm that follows)
-    assert rows(512, 56, 56, 64, 64, 3, 3, 1, 1, 1, 1) == 8
+    # default: every tile adds into one of 4 slice rows (no pre-reduction launch before the BatchNorm that follows)
+    assert rows(512, 56, 56, 64, 64, 3, 3, 1, 1, 1, 1) == 4
     old_slices = _native.query('mpr_conv_set_stat_slices', 0)      # one row per tile: the documented tilings
     try:
         _check_tile_rows(rows)
