@@ -631,7 +631,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
           for (int e = 0; e < 8; ++e) {
             q[e] = ym[e] > 0.f ? q[e] : 0.f;
             s1[e] += q[e];
-            s2[e] += q[e] * (xf[e] - bmu[e]) * bis[e];
+            s2[e] = fmaf(q[e], xf[e], s2[e]);      // (sum dz * x; xhat is formed once per tile below: conv_win.hip, bnb_finish)
           }
           *reinterpret_cast<uint4*>(p.dst + o) = pack8(q);
         } else {
@@ -648,6 +648,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     }
   });
   if (p.stats) {
+    if (BNB) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s2[e] = (s2[e] - bmu[e] * s1[e]) * bis[e];
+    }
 #pragma unroll
     for (int o = CPR; o < 64; o <<= 1)
 #pragma unroll

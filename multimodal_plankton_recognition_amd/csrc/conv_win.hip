@@ -362,15 +362,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
 #pragma unroll
       for (int e = 0; e < 8; ++e) q[e] = fmaf(xf[e], sc[e], sh[e]) > 0.f ? q[e] : 0.f;
     }
+    // (s2 collects sum dz * x here; the thread's channels are fixed, so sum dz * xhat = invstd * (s2 - mean * s1) is formed ONCE
+    //  behind the tile's rows -- bnb_finish -- instead of a subtract and a multiply per element: the fused epilogues are bound by
+    //  their VALU instructions, ~76 per 8-channel group before this)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s1[e] += q[e];
+      s2[e] = fmaf(q[e], xf[e], s2[e]);
+    }
+    return pack8(q);
+  };
+  auto bnb_finish = [&]() {
     const float4 m0 = *reinterpret_cast<const float4*>(coef + ch * 8), m1 = *reinterpret_cast<const float4*>(coef + ch * 8 + 4);
     const float4 i0 = *reinterpret_cast<const float4*>(coef + BN + ch * 8), i1 = *reinterpret_cast<const float4*>(coef + BN + ch * 8 + 4);
     const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, is[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      s1[e] += q[e];
-      s2[e] += q[e] * (xf[e] - mu[e]) * is[e];
-    }
-    return pack8(q);
+    for (int e = 0; e < 8; ++e) s2[e] = (s2[e] - mu[e] * s1[e]) * is[e];
   };
   if (!ADD) {
     // No residual: the tile is rounded to bf16 IN REGISTERS and staged as bf16 (half the LDS bytes), every wave writing
@@ -581,6 +588,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
   if (p.stats) {
     // per-thread sums -> LDS [T][16 (+1 pad)] -> CPR*16 threads each add the RPP rows of one (channel group, value):
     // one barrier, no cross-lane traffic (a shuffle tree here is 32-48 dependent ds_bpermutes)
+    if constexpr (BNB != 0) bnb_finish();      // (the coefficient table is read before the reduction overwrites the staging area)
     win_lds_barrier();
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
