@@ -27,6 +27,12 @@ def test_window_wgrad_matches_fp32(B, H, W, C, target):
         old_w = N.query('mpr_conv_set_wgrad_window', 2)          # round-1 form
         try:
             six = ops.conv_wgrad(x, dy, g, (K, C, 3, 3))
+            # the 32x32x16 form of the round-2 / round-3 loop (debug bit 6; the default is v_mfma_f32_16x16x32_bf16, whose lane
+            # groups contract over another pixel order and whose DMA swizzles the 32-byte units as well)
+            N.query('mpr_conv_set_wgrad_window', 1 | (64 << 8))
+            m32 = ops.conv_wgrad(x, dy, g, (K, C, 3, 3))
+            N.query('mpr_conv_set_wgrad_window', 2 | (64 << 8))
+            six32 = ops.conv_wgrad(x, dy, g, (K, C, 3, 3))
         finally:
             N.query('mpr_conv_set_wgrad_window', old_w)
     finally:
@@ -36,6 +42,7 @@ def test_window_wgrad_matches_fp32(B, H, W, C, target):
     assert (got - ref).abs().max().item() <= 3e-6 * scale
     assert (six - ref).abs().max().item() <= 3e-6 * scale
     assert (got - six).abs().max().item() <= 3e-6 * scale
+    assert (m32 - ref).abs().max().item() <= 3e-6 * scale and (six32 - ref).abs().max().item() <= 3e-6 * scale
 
 
 @pytest.mark.parametrize('B,H,W,C', [(40, 28, 20, 128), (9, 56, 40, 64)])

@@ -99,3 +99,50 @@ def test_l1_fused_data_gradient_epilogues_match_conv_win_kernel(B, H, W):
     finally:
         N.query('mpr_conv_set_window_variant', base)
         ops.SLICE_ARENA = arena
+
+
+@pytest.mark.parametrize('B,H,W,C', [(24, 28, 28, 128), (90, 14, 14, 256), (340, 7, 7, 512), (40, 19, 23, 128), (32, 28, 20, 192)])
+def test_window_kernel_mfma_shapes_agree_bit_for_bit(B, H, W, C):
+    """conv_win_kernel on v_mfma_f32_16x16x32_bf16 (variant bit 10, the default) against its 32x32x16 form on the wide tiles
+    (N > 64: 8 waves): forward, plain data gradient and the fused data-gradient epilogues -- outputs bit for bit (an instruction
+    pair sums the same 32-term group), BatchNorm sums to summation order."""
+    from multimodal_plankton_recognition_amd import ops, _native as N
+    K = C
+    g = ops.ConvGeom((K, C, 3, 3), 1, 1)
+    gen = torch.Generator().manual_seed(B * 7 + C)
+    w = (torch.randn(K, C, 3, 3, generator=gen) * 0.05).to(DEV)
+    wf, wd = ops.packed_weights(w, g)
+    x = torch.randn(B, H, W, C, generator=gen).to(DEV).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, K, generator=gen).to(DEV).to(torch.bfloat16)
+    res = torch.randn(B, H, W, C, generator=gen).to(DEV).to(torch.bfloat16)
+    xf = x.float().reshape(-1, C)
+
+    class St:
+        pass
+    st = St()
+    st.mean = xf.mean(0).contiguous()
+    st.invstd = (xf.var(0, unbiased=False) + 1e-5).rsqrt().contiguous()
+    st.scale = (st.invstd * 1.1).contiguous()
+    st.shift = (0.1 - st.mean * st.scale).contiguous()
+    mask_y = torch.relu(xf * st.scale + st.shift + res.float().reshape(-1, C)).to(torch.bfloat16).reshape(B, H, W, C)
+    cases = [lambda: ops.conv_fwd(x, wf, g, True), lambda: (ops.conv_dgrad(dy, wd, g, (B, H, W, C)), None),
+             lambda: (ops.conv_dgrad(dy, wd, g, (B, H, W, C), add=res), None),
+             lambda: ops.conv_dgrad_bn(dy, wd, g, (B, H, W, C), x, st, 2),
+             lambda: ops.conv_dgrad_bn(dy, wd, g, (B, H, W, C), x, st, 1, mask_y=mask_y, add=res)]
+    base = N.query('mpr_conv_set_window_variant', 5)
+    arena, ops.SLICE_ARENA = ops.SLICE_ARENA, False
+    try:
+        for fn in cases:
+            out = []
+            for var in (5 | 512, 5 | 512 | 1024):
+                N.query('mpr_conv_set_window_variant', var)
+                r = fn()
+                assert r is not None
+                out.append((r[0].clone(), None if r[1] is None else r[1].double().sum(0)))
+            (a, sa), (b, sb) = out
+            assert torch.equal(a, b)
+            if sa is not None:
+                assert (sa - sb).abs().max().item() <= 1e-3 * sb.abs().max().item()
+    finally:
+        N.query('mpr_conv_set_window_variant', base)
+        ops.SLICE_ARENA = arena
