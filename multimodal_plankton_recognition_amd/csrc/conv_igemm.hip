@@ -279,8 +279,12 @@ __device__ __forceinline__ void ig_unroll(F&& f) {      // f(IgInt<I>) ... f(IgI
 // more workgroups per CU fit the 160 KB -- the loop is bound by the LATENCY of the operand stream, i.e. by the bytes
 // in flight per CU).  Swizzle keys: 128-B rows (row >> 1) & 7 over 8 chunks, 64-B rows (row >> 2) & 3
 // over 4 chunks; both make every ds_read_b128 lane group hit 16 distinct 16-B bank slots.
-template <int WM, int WN, int STAGES, bool DGRAD, int BK = 64, bool BNB = false>
+// M16 (round 3, the default at BK = 64): the wave's 64 x 64 block as 4 x 4 v_mfma_f32_16x16x32_bf16 sub-tiles, fragment pairs
+// in four slots walked as a snake over the quadrants -- conv_win.hip's loop (same fragments, same LDS traffic, bit-identical
+// sums); the chip holds a higher clock on that shape.
+template <int WM, int WN, int STAGES, bool DGRAD, int BK = 64, bool BNB = false, bool M16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const ConvGemmParams p) {
+  static_assert(!M16 || BK == 64, "the 16x16x32 form is written for 128-byte rows");
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins do not exist in the host pass of hipcc
   constexpr int NW = WM * WN, T = 64 * NW;
   constexpr int BM = WM * 64, BN = WN * 64;
@@ -446,13 +450,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[M16 ? 1 : 2][M16 ? 1 : 2];
+  f32x4 acc16[M16 ? 4 : 1][M16 ? 4 : 1];      // [channel sub-tile of 16][pixel sub-tile of 16]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < (M16 ? 1 : 2); ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < (M16 ? 1 : 2); ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (M16 ? 4 : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (M16 ? 4 : 1); ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
 
   int issued = 0;
   for (; issued < STAGES - 1 && issued < nk; ++issued) issue_chunk(issued, issued % STAGES);
@@ -472,6 +483,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
       a_rd[t][ks] = frag_off(wm * 64 + t * 32 + frow, ks * 2 + fh);
       b_rd[t][ks] = A_BYTES + frag_off(wn * 64 + t * 32 + frow, ks * 2 + fh);
     }
+  // 16x16x32: lane -> row lane % 16 of a 16-row sub-tile, 8-channel quarter lane / 16 of a 32-deep step; sub-tile t sits 16 rows =
+  // 2048 B further with the same swizzle key
+  const int fr16 = lane & 15, fq = lane >> 4;
+  uint32_t a16[2], b16[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a16[ks] = frag_off(wm * 64 + fr16, ks * 4 + fq);
+    b16[ks] = A_BYTES + frag_off(wn * 64 + fr16, ks * 4 + fq);
+  }
   for (int kc = 0; kc < nk; ++kc) {
     // retire chunk kc: everything but the (issued - kc - 1) younger chunks of THIS wave must have landed
     const int younger = issued - kc - 1;
@@ -484,6 +504,53 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     // software-pipelined k-steps: the fragments of step ks+1 are in flight (their own registers) while the four
     // MFMAs of step ks run -- left to itself hipcc reuses one register set and exposes the LDS latency 4x per chunk.
     // The first reads go out BEFORE the next chunk's DMA is issued, so its address arithmetic hides their latency.
+    if constexpr (M16) {
+      bf16x8 S0[2], S1[2], S2[2], S3[2];
+      auto ldA = [&](bf16x8* sl, int ia, int ks) {      // pixel sub-tiles 2 ia, 2 ia + 1
+        sl[0] = *reinterpret_cast<const bf16x8*>(a + a16[ks] + (2 * ia) * 2048);
+        sl[1] = *reinterpret_cast<const bf16x8*>(a + a16[ks] + (2 * ia + 1) * 2048);
+      };
+      auto ldB = [&](bf16x8* sl, int jb, int ks) {      // channel sub-tiles 2 jb, 2 jb + 1
+        sl[0] = *reinterpret_cast<const bf16x8*>(a + b16[ks] + (2 * jb) * 2048);
+        sl[1] = *reinterpret_cast<const bf16x8*>(a + b16[ks] + (2 * jb + 1) * 2048);
+      };
+      auto quad = [&](const bf16x8* sb, const bf16x8* sa, auto JB_, auto IA_) {
+        constexpr int jb = decltype(JB_)::value, ia = decltype(IA_)::value;
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+          for (int di = 0; di < 2; ++di)
+            acc16[2 * jb + dj][2 * ia + di] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb[dj], sa[di], acc16[2 * jb + dj][2 * ia + di], 0, 0, 0);
+      };
+      ldA(S0, 0, 0); ldB(S1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (issued < nk) { issue_chunk(issued, issued % STAGES); ++issued; }
+      ldB(S2, 1, 0); ldA(S3, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S1, S0, IgInt<0>{}, IgInt<0>{});                                   // B0.0 A0.0
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S2, S0, IgInt<1>{}, IgInt<0>{});                                   // B1.0 A0.0
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(S0, 1, 1);                                                          //     A1.1 -> S0
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S2, S3, IgInt<1>{}, IgInt<1>{});                                   // B1.0 A1.0
+      __builtin_amdgcn_sched_barrier(0);
+      ldB(S2, 0, 1);                                                          //     B0.1 -> S2
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S1, S3, IgInt<0>{}, IgInt<1>{});                                   // B0.0 A1.0
+      __builtin_amdgcn_sched_barrier(0);
+      ldA(S3, 0, 1); ldB(S1, 1, 1);                                           //     A0.1 -> S3, B1.1 -> S1
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S2, S0, IgInt<0>{}, IgInt<1>{});                                   // B0.1 A1.1
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S1, S0, IgInt<1>{}, IgInt<1>{});                                   // B1.1 A1.1
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S1, S3, IgInt<1>{}, IgInt<0>{});                                   // B1.1 A0.1
+      __builtin_amdgcn_sched_barrier(0);
+      quad(S2, S3, IgInt<0>{}, IgInt<0>{});                                   // B0.1 A0.1
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     bf16x8 af[2][2], bfr[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -510,6 +577,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][i], af[cur][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
   }
 
@@ -539,7 +607,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     }
   }
   if (p.dbg & 16) {      // timing experiment: no epilogue (one store keeps the accumulators alive)
-    if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) p.dst[0] = (bf16_t)1.f;
+    if constexpr (M16) { if (acc16[0][0][0] + acc16[1][2][1] + acc16[2][1][2] + acc16[3][3][3] == 12345.f) p.dst[0] = (bf16_t)1.f; }
+    else { if (acc[0][0][0] + acc[0][M16 ? 0 : 1][1] + acc[M16 ? 0 : 1][0][2] + acc[M16 ? 0 : 1][M16 ? 0 : 1][3] == 12345.f) p.dst[0] = (bf16_t)1.f; }
     return;
   }
   // The epilogue's global operands -- residual, half-resolution shortcut gradient, ReLU-mask source, BatchNorm input: up to
@@ -586,10 +655,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     else if constexpr (slab + 1 < WM) prefetch(IgInt<(slab + 1) & 1>{}, slab + 1);
     lds_barrier();      // ring (first pass) / previous slab fully consumed
     if (wm == slab) {
+      if constexpr (M16) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+          for (int im = 0; im < 4; ++im) {
+            const int row = im * 16 + fr16;
+            const int col = wn * 64 + jn * 16 + 4 * fq;
+            float4 v = make_float4(acc16[jn][im][0], acc16[jn][im][1], acc16[jn][im][2], acc16[jn][im][3]);
+            *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
+          }
+      } else {
+#pragma unroll
+      for (int i = 0; i < (M16 ? 1 : 2); ++i)
+#pragma unroll
+        for (int j = 0; j < (M16 ? 1 : 2); ++j) {
           const int row = j * 32 + frow;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -598,6 +678,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
             *reinterpret_cast<float4*>(smem + row * CS_STRIDE + col * 4) = v;
           }
         }
+      }
     }
     lds_barrier();
 #pragma unroll
@@ -969,6 +1050,7 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   if (g_debug_drop & 2) p.wpk_bytes = 0;
   void* tok = mpr_prof_begin((mode == 1 ? 0 : 3) + (dgrad ? 1 : 0), flops, st);
   mpr_prof_bytes(tok, algo_bytes);
+  const bool m16 = !(g_debug_drop & 32);      // (debug bit 5: the 32x32x16 form, comparisons)
   if (mode == 1) {
 #define MPR_DMA5(WM_, WN_, ST_, DG_, BK_)                                                                 \
   do {                                                                                                \
@@ -978,10 +1060,20 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_set = true;                                                                                \
     }                                                                                                 \
+    static bool attr16_set = false;                                                                   \
+    if (!attr16_set) {                                                                                \
+      hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<WM_, WN_, ST_, DG_, BK_, false, (BK_ == 64)>, \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      attr16_set = true;                                                                              \
+    }                                                                                                 \
     const size_t ring_ = (size_t)ST_ * (64 * WM_ + 64 * WN_) * (2 * BK_);                             \
     const size_t epi_ = (size_t)64 * (64 * WN_ * 4 + 16);                                             \
-    conv_igemm_dma_kernel<WM_, WN_, ST_, DG_, BK_>                                                    \
-        <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                               \
+    if (m16)                                                                                          \
+      conv_igemm_dma_kernel<WM_, WN_, ST_, DG_, BK_, false, (BK_ == 64)>                              \
+          <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                             \
+    else                                                                                              \
+      conv_igemm_dma_kernel<WM_, WN_, ST_, DG_, BK_>                                                  \
+          <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                             \
   } while (0)
 #define MPR_DMA(WM_, WN_, ST_, BK_) do { if (dgrad) MPR_DMA5(WM_, WN_, ST_, true, BK_); else MPR_DMA5(WM_, WN_, ST_, false, BK_); } while (0)
     if (bnb) {
@@ -994,10 +1086,20 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_set = true;                                                                                \
     }                                                                                                 \
+    static bool attr16_set = false;                                                                   \
+    if (!attr16_set) {                                                                                \
+      hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<WM_, WN_, ST_, true, 64, true, true>,    \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      attr16_set = true;                                                                              \
+    }                                                                                                 \
     const size_t ring_ = (size_t)ST_ * (64 * WM_ + 64 * WN_) * 128;                                   \
     const size_t epi_ = (size_t)64 * (64 * WN_ * 4 + 16);                                             \
-    conv_igemm_dma_kernel<WM_, WN_, ST_, true, 64, true>                                              \
-        <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                               \
+    if (m16)                                                                                          \
+      conv_igemm_dma_kernel<WM_, WN_, ST_, true, 64, true, true>                                      \
+          <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                             \
+    else                                                                                              \
+      conv_igemm_dma_kernel<WM_, WN_, ST_, true, 64, true>                                            \
+          <<<grid, 64 * WM_ * WN_, ring_ > epi_ ? ring_ : epi_, st>>>(p);                             \
   } while (0)
       if (narrow) MPR_DMAB(4, 1, 2); else MPR_DMAB(2, 2, 2);
 #undef MPR_DMAB
