@@ -25,6 +25,8 @@ int mpr_conv_set_window_fwd_min_width(int w);
 /* tile / weight-ring variant of the shifted-window kernel (tuning knob, see conv_win.hip; default 5 | 512; bit 8: the 64 -> 64
  * filter-in-registers kernel off, bit 9: its fused data-gradient epilogues off) */
 int mpr_conv_set_window_variant(int v);
+/* 1: the LDS-DMA gather weight gradient on v_mfma_f32_16x16x32_bf16 (default 0: 32x32x16 -- measured, no gain); returns the previous value */
+int mpr_conv_debug_wgrad_mfma16(int on);
 
 /* workgroups of the persistent 64 -> 64 filter-in-registers kernel (conv_win_l1_kernel): 512 fill the chip once; more,
  * shorter-lived ones let a launch that starts beside another stream's kernel rebalance -- measured slower inside the step (default 512); returns the previous value */

@@ -199,7 +199,18 @@ __device__ __forceinline__ int wg_seg_xor(int row) {
   return CH == 16 ? (row & 3) : ((row >> 1) & 1);
 }
 
-template <int WM, int WN>
+// 16x16x32 form (round 3): 64-B segments XORed with the low row bits as below, and the two 32-B units of a segment swapped by
+// bit 2 of the row -- a half-wave of the transposing reads then covers eight consecutive pixel rows x 32 B in eight distinct
+// 32-B bank groups whatever the row stride (rows of 512 B take the segment key from two row bits instead of one)
+template <int CH>
+__device__ __forceinline__ int wg_seg_xor16(int row) {
+  return CH % 16 == 0 ? (row & 3) : ((row >> 1) & 1);
+}
+
+// M16: the products as v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on that shape: DESIGN.md section 9): a chunk is two
+// 32-pixel steps, a wave's 64 x 64 block 4 x 4 sub-tiles; lane group g = lane / 16 contracts over pixels 4 g .. 4 g + 3 (first
+// read) and 16 + 4 g .. (second read) of a step for BOTH operands (conv_wgrad_win.hip).
+template <int WM, int WN, bool M16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WM * WN;
@@ -239,7 +250,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   for (int j = 0; j < A_IT; ++j) {
     const int q = (wid + j * NW) * 64 + lane;
     const int row = q / CA, pc = q % CA;
-    const int lc = (((pc >> 2) ^ wg_seg_xor<CA>(row)) << 2) | (pc & 3);
+    int lc = (((pc >> 2) ^ (M16 ? wg_seg_xor16<CA>(row) : wg_seg_xor<CA>(row))) << 2) | (pc & 3);
+    if (M16) lc ^= ((row >> 2) & 1) << 1;
     a_row[j] = row;
     a_off[j] = (m0 + lc * 8 < p.K) ? (uint32_t)((row * p.K + m0 + lc * 8) * 2) : 0xFFFFFFF0u;
   }
@@ -249,7 +261,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
   for (int j = 0; j < B_IT; ++j) {
     const int q = (wid + j * NW) * 64 + lane;
     const int row = q / CB, pc = q % CB;
-    const int lc = (((pc >> 2) ^ wg_seg_xor<CB>(row)) << 2) | (pc & 3);
+    int lc = (((pc >> 2) ^ (M16 ? wg_seg_xor16<CB>(row) : wg_seg_xor<CB>(row))) << 2) | (pc & 3);
+    if (M16) lc ^= ((row >> 2) & 1) << 1;
     const int n = n0 + lc * 8;
     b_row[j] = row;
     b_off[j] = 0;
@@ -317,24 +330,42 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[M16 ? 1 : 2][M16 ? 1 : 2];
+  f32x4 acc16[M16 ? 4 : 1][M16 ? 4 : 1];      // [sub-tile of 16 output channels][sub-tile of 16 (tap, channel) columns]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < (M16 ? 1 : 2); ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < (M16 ? 1 : 2); ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (M16 ? 4 : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (M16 ? 4 : 1); ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
 
   // transposing-read lane geometry (see conv_wgrad_kernel); the 64-B segment XOR is lane-constant because the
   // pixel row of a read is (multiple of 4) + lq
   const int g16 = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
-  uint32_t a_rd[2], b_rd[2];
+  uint32_t a_rd[M16 ? 4 : 2], b_rd[M16 ? 4 : 2];
+  if constexpr (M16) {
+    // sub-tile t (16 columns = a 32-B unit): segment wm * 2 + t / 2, unit t % 2; rows 4 g16 + lq (+ 16: second read; + 32: next step)
+    const int rowl = 4 * g16 + lq;
+    const int inseg = (4 * lp) * 2;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a_rd[t] = rowl * ASTR + (((wm * 2 + (t >> 1)) ^ wg_seg_xor16<CA>(lq)) << 6) + (((t & 1) ^ (g16 & 1)) << 5) + inseg;
+      b_rd[t] = A_BYTES + rowl * BSTR + (((wn * 2 + (t >> 1)) ^ wg_seg_xor16<CB>(lq)) << 6) + (((t & 1) ^ (g16 & 1)) << 5) + inseg;
+    }
+  } else {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int rowl = 8 * (g16 >> 1) + lq;
     const int inseg = (16 * (g16 & 1) + 4 * lp) * 2;
     a_rd[t] = rowl * ASTR + (((wm * 2 + t) ^ wg_seg_xor<CA>(lq)) << 6) + inseg;
     b_rd[t] = A_BYTES + rowl * BSTR + (((wn * 2 + t) ^ wg_seg_xor<CB>(lq)) << 6) + inseg;
+  }
   }
 
   WG_STAMP(1);
@@ -358,6 +389,50 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
     // for the next chunk's DMA it has just issued.  Completion is by hand: the s_waitcnt lgkmcnt(0) below carries the
     // destination registers as in/out operands, so every consumer is ordered behind it.
     typedef __attribute__((ext_vector_type(8))) short s16x8;
+    if constexpr (M16) {
+      // (the 16-wave tile has 128 VGPRs per wave: one fragment set -- its four waves per SIMD hide the reads of the next step
+      //  behind each other's MFMAs)
+      constexpr int NB = NW >= 16 ? 1 : 2;
+      s16x4 ra[NB][4][2], rb[NB][4][2];      // [buffer][sub-tile][half]
+      auto load_frags = [&](int buf, int ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t pa = a + a_rd[t] + ks * 32 * ASTR;
+          const uint32_t pb = a + b_rd[t] + ks * 32 * BSTR;
+          ra[buf][t][0] = wg_read_tr(pa);
+          ra[buf][t][1] = wg_read_tr(pa + 16 * ASTR);
+          rb[buf][t][0] = wg_read_tr(pb);
+          rb[buf][t][1] = wg_read_tr(pb + 16 * BSTR);
+        }
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int cur = NB == 2 ? (ks & 1) : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[cur][0][0]), "+v"(ra[cur][0][1]), "+v"(ra[cur][1][0]), "+v"(ra[cur][1][1]),
+                       "+v"(ra[cur][2][0]), "+v"(ra[cur][2][1]), "+v"(ra[cur][3][0]), "+v"(ra[cur][3][1]),
+                       "+v"(rb[cur][0][0]), "+v"(rb[cur][0][1]), "+v"(rb[cur][1][0]), "+v"(rb[cur][1][1]),
+                       "+v"(rb[cur][2][0]), "+v"(rb[cur][2][1]), "+v"(rb[cur][3][0]), "+v"(rb[cur][3][1])
+                     :
+                     : "memory");
+        if (NB == 2 && ks < 1) load_frags(cur ^ 1, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          af[t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(ra[cur][t][0], ra[cur][t][1], 0, 1, 2, 3, 4, 5, 6, 7));
+          bfr[t] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(rb[cur][t][0], rb[cur][t][1], 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc16[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (NB == 1 && ks < 1) load_frags(0, ks + 1);
+      }
+    } else {
     s16x4 ra[2][2][2], rb[2][2][2];      // [buffer][tile][half]
     auto load_frags = [&](int buf, int ks) {
 #pragma unroll
@@ -394,14 +469,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
   }
 
   WG_STAMP(2);
   const int ln = lane & 31, lh = lane >> 5;
+  if constexpr (M16) {
+    // 16 x 16 sub-tiles: lane -> column lane % 16, rows 4 (lane / 16) + e
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + e;
+          if (k < p.K && n < p.Ng) atomicAdd(p.dw + (size_t)k * p.Ng + n, acc16[i][j][e]);
+        }
+      }
+  } else {
+#pragma unroll
+  for (int i = 0; i < (M16 ? 1 : 2); ++i)
+#pragma unroll
+    for (int j = 0; j < (M16 ? 1 : 2); ++j) {
       const int n = n0 + wn * 64 + j * 32 + ln;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -409,6 +499,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_dma_kernel(const Wgra
         if (k < p.K && n < p.Ng) atomicAdd(p.dw + (size_t)k * p.Ng + n, acc[i][j][e]);
       }
     }
+  }
   WG_STAMP(3);
 #undef WG_STAMP
 #endif   // __HIP_DEVICE_COMPILE__
@@ -450,6 +541,9 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ src, float* __rest
 }
 
 static int g_wgrad_dma_min_pix = 16384;
+// 1: the LDS-DMA gather kernel on v_mfma_f32_16x16x32_bf16.  Built and tested (tests/test_wgrad_gather_mfma_gpu.py), NOT the default:
+// C3 9.334 vs 9.329 ms per step, C5's per-GPU share 30.52 vs 30.32 (its 16-wave tile has registers for ONE fragment set in this form)
+static int g_wgrad_mfma16 = 0;
 
 extern "C" {
 
@@ -459,6 +553,12 @@ bool mpr_wgw_eligible(long long Mpix, int H, int W, int C, int K, int R, int S, 
 int mpr_wgw_launch(const void* x, const void* dy, float* dw, int B, int H, int W, int C, int K, int target_wgs,
                    float* scratch, long long scratch_floats, hipStream_t st);
 void mpr_wgw_take_scratch(float** buf, long long* floats);
+
+int mpr_conv_debug_wgrad_mfma16(int on) {   // timing / test knob; returns the previous value
+  const int old = g_wgrad_mfma16;
+  g_wgrad_mfma16 = on;
+  return old;
+}
 
 int mpr_conv_set_wgrad_dma_min_pixels(int pixels) {   // tuning / test knob; returns the previous value
   const int old = g_wgrad_dma_min_pix;
@@ -567,9 +667,12 @@ static int wgrad_impl(const void* x, const void* dy, float* workspace, float* dw
     if (!attr_set) {                                                                                  \
       hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<WM_, WN_>,                               \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<WM_, WN_, true>,                         \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_set = true;                                                                                \
     }                                                                                                 \
-    conv_wgrad_dma_kernel<WM_, WN_><<<grid, 64 * WM_ * WN_, smem_, st>>>(p);                          \
+    if (!g_wgrad_mfma16) conv_wgrad_dma_kernel<WM_, WN_><<<grid, 64 * WM_ * WN_, smem_, st>>>(p);     \
+    else conv_wgrad_dma_kernel<WM_, WN_, true><<<grid, 64 * WM_ * WN_, smem_, st>>>(p);               \
   } while (0)
     if (WM == 1 && WN == 1) MPR_WGD(1, 1);
     else if (WM == 1 && WN == 2) MPR_WGD(1, 2);
