@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 CARD = os.path.join(ROOT, 'model_cards', 'resnet18_cnn_2_512_clip.yaml')
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 C3_STEP_TFLOP = 5.36                    # algorithmic work of one batch-512 C3 step
+PROF_EVERY = 10                         # per-launch HIP events (roofline) on every 10th timed step: they cost ~0.4 ms on a step
 
 
 def synthetic_batch(B, T, device, seed, transformer=False):
@@ -203,8 +204,8 @@ def main():
     marks[0].record()
     for i in range(args.steps):
         # the per-launch HIP events of the roofline measurement cost ~5 us of stream bubble each (~0.4 ms per step):
-        # they are recorded on every 4th step of the timed region only
-        lib.mpr_prof_enable(1 if i % 4 == 0 else 0)
+        # they are recorded on every PROF_EVERY-th step of the timed region only (two of the default twenty)
+        lib.mpr_prof_enable(1 if i % PROF_EVERY == 0 else 0)
         loss = one_step()
         marks[i + 1].record()
     torch.cuda.synchronize()
@@ -217,7 +218,7 @@ def main():
     loss_val = float(loss.detach())
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2]
-    unprofiled = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps) if i % 4)
+    unprofiled = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps) if i % PROF_EVERY)
     median_unprofiled = unprofiled[len(unprofiled) // 2] if unprofiled else median_ms
 
     def collect(kind):
@@ -226,7 +227,7 @@ def main():
         return ms.value, work.value, n.value
 
     if rank == 0:
-        prof_steps = len(range(0, args.steps, 4))
+        prof_steps = len(range(0, args.steps, PROF_EVERY))
         ms_per_step = elapsed / args.steps * 1e3
 
         def family(kinds, name, pmc_key, algo_kinds=None):
@@ -289,7 +290,7 @@ def main():
                                          'work': f'{C3_STEP_TFLOP} TFLOP per batch-512 step (SURVEY 8d: 10.47 GFLOP per sample)'}
                                         if c3 else None),
                          'alone': isolated_conv_rate(B, dev) if c3 else None,
-                         'note': 'achieved / avg_launch_us: hipEvent-timed on the launch stream INSIDE every 4th timed step, i.e. '
+                         'note': 'achieved / avg_launch_us: hipEvent-timed on the launch stream INSIDE every 10th timed step, i.e. '
                                  'while the profile branch and the weight-gradient kernels run beside it on other streams; '
                                  '"alone" is the same kernel on the four ResNet-18 body shapes with the GPU to itself; '
                                  'ms_per_step is wall clock over all steps, ms_per_step_median the median of per-step HIP '
