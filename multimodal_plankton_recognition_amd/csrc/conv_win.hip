@@ -384,7 +384,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
     // its own rows at once -- one pass of 256 rows at BN = 64, two of 128 rows at BN = 128 (LDS capacity) -- and the
     // read side hands finished 16-B channel groups to the global store.  (The slab path below serialises the waves and
     // moves fp32; it is kept for the fused residual add, which must see the unrounded accumulator.)
-    constexpr int EP = BN == 64 ? 1 : 2;          // passes
+    // (the fused BatchNorm-backward epilogue of the 128-channel tile also stages ALL 256 rows at once -- 69.6 KB, inside the
+    //  window + ring allocation -- so that no wave holds its accumulators while another pass is read: its rows then fit the 128
+    //  VGPRs in ONE burst of global loads instead of four, each of which was a full round trip: round-3 probe, 16.4 K of the
+    //  workgroup's 73.7 K cycles at layer2)
+    constexpr int EP = (BN == 64 || BNB != 0) ? 1 : 2;          // passes
     constexpr int RPASS = BM / EP;                // rows per pass
     constexpr int RS = BN * 2 + 16;               // staged row stride (bytes): 16 rows of a write group hit 16 bank pairs
     static_assert(RPASS % (TM * 32) == 0 && RPASS % RPP == 0, "a pass is whole wave rows");
@@ -428,9 +432,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_win
       pr_ew += e1 - e0;
       // all of this thread's rows are read in one burst (unconditionally: the LDS latency is paid once, not per row),
       // the raster decode runs underneath, then the stores go out
-      // (the fused BatchNorm-backward variant of the 8-wave tile takes its rows in two halves: with the waves of the other
-      //  pass still holding their accumulators, four rows of (tile, BatchNorm input, mask) groups do not fit 128 VGPRs)
-      constexpr int NSUB = (BNB && T == 512) ? 2 : 1;
+      constexpr int NSUB = (BNB == 1 && T == 512) ? 2 : 1;      // (mask from the block output: three maps per row -- two bursts)
       constexpr int NR = RPASS / RPP / NSUB;
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub) {
@@ -1516,7 +1518,7 @@ int mpr_win_launch(bool dgrad, const void* src, const void* wpk, void* dst, cons
     /* coefficient table: behind what the epilogue stages (<= 36.9 KB without the skip add, 69.6 KB with it at 64    \
        channels, 33.8 KB at 128), inside the window + ring allocation whenever that is large enough: two workgroups  \
        of the 64-channel tile at W = 56 fill the CU's 160 KB to within 2 KB */                                       \
-    const size_t tab_ = (size_t)((ADD_ && (WN_ * TN_ * 32) == 64) ? 72 : 40) * 1024;                       \
+    const size_t tab_ = (size_t)(((ADD_ && (WN_ * TN_ * 32) == 64) || (!ADD_ && (WN_ * TN_ * 32) == 128)) ? 72 : 40) * 1024; \
     const size_t need_ = tab_ + 4 * (WN_ * TN_ * 32) * sizeof(float);                                      \
     size_t body_ = ring_ > epi_ ? ring_ : epi_;                                                            \
     if (body_ < need_) body_ = need_;                                                                      \
