@@ -1000,6 +1000,10 @@ static inline void igemm_config(long long M, int Nout, int srcC, int taps, int* 
     *mode = 1; *BN = narrow ? 64 : ((big || (vw >= 7 && vw <= 9 && Nout >= 256)) ? 256 : 128);
     *BM = narrow ? (g_variant_narrow == 2 ? 128 : 256)
                  : ((big || vw == 0 || vw == 5 || vw == 6 || ((vw == 7 || vw == 8) && Nout >= 256)) ? 256 : 128);
+  } else if (srcC % 32 == 0 && taps <= 32 && M >= g_dma_min_rows) {
+    // source channels a multiple of 32 only (EfficientNet-B0's 96 / 480 / 672-channel maps): the LDS-DMA ring on 64-byte rows
+    // (32-deep chunks) instead of the register-staged kernel
+    *mode = 1; *BM = narrow ? 256 : 128; *BN = narrow ? 64 : 128;
   } else {
     *mode = 0; *BM = narrow ? 256 : 128; *BN = narrow ? 64 : 128;
   }
@@ -1103,6 +1107,10 @@ static int launch_igemm(bool dgrad, ConvGemmParams& p, hipStream_t st) {
   } while (0)
       if (narrow) MPR_DMAB(4, 1, 2); else MPR_DMAB(2, 2, 2);
 #undef MPR_DMAB
+    } else if (p.sC % 64 != 0) {      // 32-deep chunks (see igemm_config); tiles as the register-staged kernel's
+      if (narrow) MPR_DMA(4, 1, 4, 32);
+      else if (s2dgrad) MPR_DMA5(4, 2, 3, true, 32);
+      else MPR_DMA(2, 2, 3, 32);
     } else if (narrow) {
       switch (g_variant_narrow) {
         case 1: MPR_DMA(4, 1, 3, 64); break;
@@ -1293,8 +1301,9 @@ int mpr_conv_dgrad_s2_bn(const void* dy, const void* w_dgrad, void* dz, const vo
                          int B, int H, int W, int C, int K, int R, int S, int sh, int sw, int ph, int pw, void* stream) {
   MPR_REQUIRE(mask_y && bn_x && mean && invstd && slices && nslices > 0, "mpr_conv_dgrad_s2_bn: null pointer");
   const int P = (H + 2 * ph - R) / sh + 1, Q = (W + 2 * pw - S) / sw + 1;
-  MPR_REQUIRE(C % 8 == 0 && K % 8 == 0 && dgrad_parity_path(B, H, W, C, K, R, S, sh, sw) && P == H / 2 && Q == W / 2,
-              "mpr_conv_dgrad_s2_bn: geometry not on the parity-class path (ask mpr_conv_dgrad_add_even_supported)");
+  MPR_REQUIRE(C % 8 == 0 && K % 64 == 0 && dgrad_parity_path(B, H, W, C, K, R, S, sh, sw) && P == H / 2 && Q == W / 2,
+              "mpr_conv_dgrad_s2_bn: geometry not on the parity-class path with 64-deep chunks (K %% 64 == 0; ask "
+              "mpr_conv_dgrad_add_even_supported)");
   DgradBnb bnb = {mask_y, bn_x, mean, invstd, slices, nslices, prezeroed};
   return conv_dgrad_impl(dy, w_dgrad, dz, nullptr, add_even, B, H, W, C, K, R, S, sh, sw, ph, pw, stream, &bnb);
 }

@@ -13,73 +13,70 @@
 __device__ __forceinline__ float se_sigmoid(float z) { return 1.f / (1.f + expf(-z)); }
 
 // z1[b][j] = W1[j] . pooled[b] + b1[j];  r = silu(z1);  gate[b][c] = sigmoid(W2[c] . r + b2[c])
-// A workgroup takes IB = 4 images, so that every weight it reads serves four rows (one image per workgroup re-read both
-// filters 256 times per launch: 113 MB through L2 for the 1152-wide blocks, 89 us); W2 is read through LDS tiles of 64 channels
-// x rd so that the global reads are contiguous (a thread per channel walking its own row was a 192-byte stride across lanes).
-#define SE_IB 4
+// One workgroup per image.  First product: a thread owns channels c, c + 256, ... and ALL rd bottleneck rows at once (rd
+// accumulators), so every W1 load is coalesced across the workgroup and rd x C / 256 of them are in flight together; the partial
+// sums meet by wave shuffles + LDS.  (A wave per bottleneck row walked its row in 18 dependent-latency steps, twelve rows in
+// sequence: 89 us for the 1152-wide blocks; four images per workgroup to share the weight reads made it 116 -- the weights come
+// from L2 either way, the parallelism was the point.)  Second product: a thread per channel on its own W2 row.
+template <int RDP>
 __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
                                                          const float* __restrict__ b1, const float* __restrict__ w2,
                                                          const float* __restrict__ b2, float* __restrict__ z1,
-                                                         float* __restrict__ r, float* __restrict__ gate, int B, int C, int rd) {
-  extern __shared__ float sm[];
-  float* const sp = sm;                       // pooled rows [IB][C]
-  float* const sh = sm + SE_IB * C;           // hidden vectors [IB][rd]
-  float* const sw = sh + SE_IB * rd;          // W2 tile [256 channels][rd + 1]
-  const int b0 = blockIdx.x * SE_IB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nb = B - b0 < SE_IB ? B - b0 : SE_IB;
-  for (int i = tid; i < SE_IB * C; i += 256) sp[i] = i < nb * C ? pooled[(size_t)b0 * C + i] : 0.f;
-  __syncthreads();
-  for (int j = wave; j < rd; j += 4) {
-    const float* wr = w1 + (size_t)j * C;
-    float a[SE_IB];
+                                                         float* __restrict__ r, float* __restrict__ gate, int C, int rd) {
+  __shared__ float part[4][RDP];
+  __shared__ float sh[RDP];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[RDP];
 #pragma unroll
-    for (int i = 0; i < SE_IB; ++i) a[i] = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float wv = wr[c];
+  for (int j = 0; j < RDP; ++j) acc[j] = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float pv = pooled[(size_t)b * C + c];
 #pragma unroll
-      for (int i = 0; i < SE_IB; ++i) a[i] = fmaf(wv, sp[i * C + c], a[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < SE_IB; ++i) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) a[i] += __shfl_xor(a[i], off);
-    }
-    if (lane == 0) {
-      const float bj = b1[j];
-#pragma unroll
-      for (int i = 0; i < SE_IB; ++i) {
-        const float z = a[i] + bj;
-        const float h = z * se_sigmoid(z);
-        if (i < nb) {
-          z1[(size_t)(b0 + i) * rd + j] = z;
-          r[(size_t)(b0 + i) * rd + j] = h;
-        }
-        sh[i * rd + j] = h;
-      }
+    // (rows past rd: the last row again, times zero -- NO branch per row: behind a branch every load waits for its own use
+    //  before the next is issued, 240 serial round trips per thread: 74 us per workgroup for 110 K multiply-adds)
+    for (int j = 0; j < RDP; ++j) {
+      const float wv = w1[(size_t)(j < rd ? j : rd - 1) * C + c];
+      acc[j] = fmaf(j < rd ? wv : 0.f, pv, acc[j]);
     }
   }
+#pragma unroll
+  for (int j = 0; j < RDP; ++j) {
+    float a = acc[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) part[wave][j] = a;
+  }
+  __syncthreads();
+  if (tid < rd) {
+    const float z = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]) + b1[tid];
+    const float h = z * se_sigmoid(z);
+    z1[(size_t)b * rd + tid] = z;
+    r[(size_t)b * rd + tid] = h;
+    sh[tid] = h;
+  }
+  __syncthreads();
+  // (W2 through LDS tiles of 256 channels x rd: the global reads are contiguous; a thread walking its own row strides the lanes
+  //  by rd floats -- 64 cache lines per load instruction)
+  extern __shared__ float sw[];      // [256][rd + 1]
   for (int c0 = 0; c0 < C; c0 += 256) {
-    __syncthreads();      // (first pass: the hidden vectors are complete; later: the previous tile has been consumed)
+    if (c0) __syncthreads();
     const int nc = C - c0 < 256 ? C - c0 : 256;
     for (int i = tid; i < nc * rd; i += 256) sw[(i / rd) * (rd + 1) + i % rd] = w2[(size_t)c0 * rd + i];
     __syncthreads();
     if (tid < nc) {
       const int c = c0 + tid;
-      const float bc = b2[c];
-      float a[SE_IB];
+      float a = b2[c];
+      const float* wr = sw + tid * (rd + 1);
 #pragma unroll
-      for (int i = 0; i < SE_IB; ++i) a[i] = bc;
-      for (int j = 0; j < rd; ++j) {
-        const float wv = sw[tid * (rd + 1) + j];
-#pragma unroll
-        for (int i = 0; i < SE_IB; ++i) a[i] = fmaf(wv, sh[i * rd + j], a[i]);
+      for (int j = 0; j < RDP; ++j) {
+        const int jc = j < rd ? j : rd - 1;
+        a = fmaf(j < rd ? wr[jc] : 0.f, sh[jc], a);
       }
-#pragma unroll
-      for (int i = 0; i < SE_IB; ++i)
-        if (i < nb) gate[(size_t)(b0 + i) * C + c] = se_sigmoid(a[i]);
+      gate[(size_t)b * C + c] = se_sigmoid(a);
     }
   }
 }
+
 
 // per image: dz2 = dgate * gate (1 - gate);  dr = W2^T dz2;  dz1 = dr * silu'(z1);  dpooled = scale * W1^T dz1
 // (+ the bias gradients db2 += dz2, db1 += dz1 by fp32 atomics: one per image and element)
@@ -110,8 +107,10 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     const float d = sd[c];
     const float* wr = w2 + (size_t)c * rd;
 #pragma unroll
-    for (int j = 0; j < RDP; ++j)
-      if (j < rd) pr[j] = fmaf(wr[j], d, pr[j]);
+    for (int j = 0; j < RDP; ++j) {
+      const float wv = wr[j < rd ? j : rd - 1];
+      pr[j] = fmaf(j < rd ? wv : 0.f, d, pr[j]);
+    }
   }
 #pragma unroll
   for (int j = 0; j < RDP; ++j) red[tid * (RDP + 1) + j] = pr[j];
@@ -156,11 +155,12 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* __restri
     const float* rr = r + (size_t)b * rd;
     const float* dd = dz1 + (size_t)b * rd;
 #pragma unroll
-    for (int j = 0; j < RDP; ++j)
-      if (j < rd) {
-        a2[j] = fmaf(d2, rr[j], a2[j]);
-        a1[j] = fmaf(dd[j], pl, a1[j]);
-      }
+    for (int j = 0; j < RDP; ++j) {
+      const int jc = j < rd ? j : rd - 1;
+      const float rv = rr[jc], dv = dd[jc];
+      a2[j] = fmaf(d2, j < rd ? rv : 0.f, a2[j]);
+      a1[j] = fmaf(j < rd ? dv : 0.f, pl, a1[j]);
+    }
   }
 #pragma unroll
   for (int j0 = 0; j0 < RDP; j0 += JC) {
@@ -211,14 +211,18 @@ int mpr_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const 
                    float* gate, int B, int C, int rd, void* stream) {
   MPR_REQUIRE(pooled && w1 && b1 && w2 && b2 && z1 && r && gate && B > 0 && C > 0 && rd > 0 && rd <= SE_RD_MAX && C <= 8192,
               "mpr_se_mlp_fwd: bad arguments (rd=%d, at most %d)", rd, SE_RD_MAX);
-  const size_t lds = sizeof(float) * ((size_t)SE_IB * (C + rd) + 256 * (rd + 1));
+  const int rdp = rd <= 8 ? 8 : rd <= 16 ? 16 : rd <= 32 ? 32 : 64;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t ldsf = sizeof(float) * 256 * (size_t)(rd + 1);      // <= 66.5 KB
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)se_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)se_mlp_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr_set = true;
   }
-  MPR_REQUIRE(lds <= 160 * 1024, "mpr_se_mlp_fwd: C=%d does not fit the workgroup's LDS", C);
-  se_mlp_fwd_kernel<<<ceil_div(B, SE_IB), 256, lds, (hipStream_t)stream>>>(pooled, w1, b1, w2, b2, z1, r, gate, B, C, rd);
+  if (rdp == 8) se_mlp_fwd_kernel<8><<<B, 256, ldsf, st>>>(pooled, w1, b1, w2, b2, z1, r, gate, C, rd);
+  else if (rdp == 16) se_mlp_fwd_kernel<16><<<B, 256, ldsf, st>>>(pooled, w1, b1, w2, b2, z1, r, gate, C, rd);
+  else if (rdp == 32) se_mlp_fwd_kernel<32><<<B, 256, ldsf, st>>>(pooled, w1, b1, w2, b2, z1, r, gate, C, rd);
+  else se_mlp_fwd_kernel<64><<<B, 256, ldsf, st>>>(pooled, w1, b1, w2, b2, z1, r, gate, C, rd);
   MPR_LAUNCH_CHECK("se_mlp_fwd_kernel");
   return MPR_OK;
 }

@@ -157,12 +157,15 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 // Here a thread owns 8 output channels x ALL nine taps (72 accumulators) and walks pixels: lanes of a wave = cgn channel groups x
 // 64 / cgn consecutive pixels (the gradient rows of a wave are one contiguous run, the nine x values of a pixel three short
 // runs); lanes of equal channel group meet by wave shuffles, the block's waves in LDS, blocks by fp32 atomics.
-__global__ __launch_bounds__(256) void stem_wgrad_c1k3_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                              float* __restrict__ dw, StemGeom g, int pix_per_block) {
-  __shared__ float red[4][64][9];
+// (Workgroups of 16 waves and at most one per CU: every workgroup ends in K x 9 fp32 atomics on the SAME addresses, and those
+//  serialise at the memory side at ~0.4 us each -- 2048 workgroups of four waves spent 800 of their 840 us there and starved the
+//  profile branch's kernels on the other stream meanwhile.)
+__global__ __launch_bounds__(1024) void stem_wgrad_c1k3_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                               float* __restrict__ dw, StemGeom g, int pix_per_block) {
+  __shared__ float red[16][64][9];
   const int cgn = g.K >> 3;                    // power of two, <= 64 (host)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cg = lane % cgn, pl = tid / cgn, npl = 256 / cgn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwv = blockDim.x >> 6;
+  const int cg = lane % cgn, pl = tid / cgn, npl = (int)blockDim.x / cgn;
   float acc[9][8];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -208,8 +211,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_c1k3_kernel(const float* __res
     __syncthreads();
     if (wave == 0 && lane < cgn) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
-        atomicAdd(dw + (size_t)(cg * 8 + e) * 9 + t, (red[0][lane][t] + red[1][lane][t]) + (red[2][lane][t] + red[3][lane][t]));
+      for (int t = 0; t < 9; ++t) {
+        float a = 0.f;
+        for (int w2 = 0; w2 < nwv; ++w2) a += red[w2][lane][t];
+        atomicAdd(dw + (size_t)(cg * 8 + e) * 9 + t, a);
+      }
     }
   }
 }
@@ -334,9 +340,9 @@ int mpr_stem_wgrad(const float* x, const void* dy, float* dw, int accumulate, in
   const int npix = B * g.P * g.Q;
   const int cgn = K / 8;
   if (Cin == 1 && R == 3 && S == 3 && cgn <= 64 && (cgn & (cgn - 1)) == 0) {
-    int ppb1 = ceil_div(npix, 2048);
-    if (ppb1 < 256) ppb1 = 256;
-    stem_wgrad_c1k3_kernel<<<ceil_div(npix, ppb1), 256, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb1);
+    int ppb1 = ceil_div(npix, 256);
+    if (ppb1 < 1024) ppb1 = 1024;
+    stem_wgrad_c1k3_kernel<<<ceil_div(npix, ppb1), 1024, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb1);
     MPR_LAUNCH_CHECK("stem_wgrad_c1k3_kernel");
     return MPR_OK;
   }

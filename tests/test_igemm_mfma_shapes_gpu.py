@@ -43,3 +43,29 @@ def test_dma_implicit_gemm_mfma_shapes_agree(B, H, W, C, K, k, stride, pad):
     assert (s6 - s3).abs().max().item() <= 1e-4 * s3.abs().max().item()
     assert (y6.float() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item()
     assert (d6.float() - refd).abs().max().item() <= 8e-3 * refd.abs().max().item()
+
+
+@pytest.mark.parametrize('B,H,W,C,K,k,stride,pad', [(24, 28, 28, 96, 24, 1, 1, 0), (90, 14, 14, 480, 112, 1, 1, 0),
+                                                    (90, 14, 14, 672, 192, 1, 1, 0), (24, 28, 28, 96, 160, 3, 2, 1),
+                                                    (24, 28, 28, 160, 96, 1, 1, 0)])
+def test_dma_implicit_gemm_on_32_channel_multiples(B, H, W, C, K, k, stride, pad):
+    """Source channels a multiple of 32 but not of 64 (EfficientNet-B0's 96 / 480 / 672-wide maps,
+    /root/reference/model_cards/example_multi.yaml:9): the LDS-DMA ring on 32-deep chunks, forward (source = C) and data gradient
+    (source = K), against fp32 torch on the same bf16-rounded operands."""
+    from multimodal_plankton_recognition_amd import ops
+    g = ops.ConvGeom((K, C, k, k), stride, pad)
+    gen = torch.Generator().manual_seed(B + C + K)
+    w = (torch.randn(K, C, k, k, generator=gen) * 0.05).to(DEV)
+    wf, wd = ops.packed_weights(w, g)
+    x = torch.randn(B, H, W, C, generator=gen).to(DEV).to(torch.bfloat16)
+    wq = w.to(torch.bfloat16).float()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wq, None, stride, pad).permute(0, 2, 3, 1)
+    dy = torch.randn(*ref.shape, generator=gen).to(DEV).to(torch.bfloat16)
+    refd = torch.nn.grad.conv2d_input((B, C, H, W), wq, dy.float().permute(0, 3, 1, 2), stride, pad).permute(0, 2, 3, 1)
+    y, st = ops.conv_fwd(x, wf, g, True)
+    dx = ops.conv_dgrad(dy, wd, g, tuple(x.shape))
+    assert (y.float() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item()
+    assert (dx.float() - refd).abs().max().item() <= 8e-3 * refd.abs().max().item()
+    yq = y.double().reshape(-1, K)
+    want = torch.stack([yq.sum(0), (yq * yq).sum(0)])
+    assert (st.double().sum(0) - want).abs().max().item() <= 1e-4 * want.abs().max().item()
