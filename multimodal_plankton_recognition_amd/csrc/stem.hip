@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // (block, element)).  Thread = (8 output channels) x (a strided subset of the taps).
 template <int MAXT>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                         float* __restrict__ dw, StemGeom g, int pix_per_block) {
+                                                         float* __restrict__ dw, StemGeom g, int pix_per_block, int dense_ok) {
   const int cgn = g.K >> 3;
   const int nthr = blockDim.x;
   const int cg = threadIdx.x % cgn;
@@ -142,6 +142,23 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(xv[u][j], d[e], acc[j][e]);
     }
+  }
+  // The block's K x taps sums leave through LDS as ONE dense run of atomics (consecutive lanes -> consecutive addresses: a wave
+  // instruction is two cache-line operations at the memory side).  Straight from the registers a lane's address is
+  // (8 cg + e) * taps + t -- every lane another cache line, K x taps line operations per block: that, not the arithmetic, was
+  // this kernel's time (round 3).
+  extern __shared__ float dense[];      // [K * taps] (host: <= 48 KB, else the scattered form)
+  if (dense_ok) {
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+      if (tv[j]) {
+        const int t = tl + j * ntl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dense[(cg * 8 + e) * g.taps + t] = acc[j][e];
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.K * g.taps; i += nthr) atomicAdd(dw + i, dense[i]);
+    return;
   }
 #pragma unroll
   for (int j = 0; j < MAXT; ++j)
@@ -201,22 +218,20 @@ __global__ __launch_bounds__(1024) void stem_wgrad_c1k3_kernel(const float* __re
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[t][e] += __shfl_xor(acc[t][e], off);
+  // waves -> LDS [wave][K * 9] in dw's own order, then ONE dense run of atomics (consecutive lanes -> consecutive addresses)
+  float* const dense = &red[0][0][0];      // 16 x 576 floats: K <= 64 (host)
+  __syncthreads();
+  if (lane < cgn) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    __syncthreads();
-    if (lane < cgn) {
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) red[wave][lane][t] = acc[t][e];
-    }
-    __syncthreads();
-    if (wave == 0 && lane < cgn) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        float a = 0.f;
-        for (int w2 = 0; w2 < nwv; ++w2) a += red[w2][lane][t];
-        atomicAdd(dw + (size_t)(cg * 8 + e) * 9 + t, a);
-      }
-    }
+      for (int t = 0; t < 9; ++t) dense[wave * 576 + (cg * 8 + e) * 9 + t] = acc[t][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < g.K * 9; i += (int)blockDim.x) {
+    float a = 0.f;
+    for (int w2 = 0; w2 < nwv; ++w2) a += dense[w2 * 576 + i];
+    atomicAdd(dw + i, a);
   }
 }
 
@@ -339,7 +354,7 @@ int mpr_stem_wgrad(const float* x, const void* dy, float* dw, int accumulate, in
   if (!accumulate) MPR_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * g.taps, st));
   const int npix = B * g.P * g.Q;
   const int cgn = K / 8;
-  if (Cin == 1 && R == 3 && S == 3 && cgn <= 64 && (cgn & (cgn - 1)) == 0) {
+  if (Cin == 1 && R == 3 && S == 3 && cgn <= 8 && (cgn & (cgn - 1)) == 0) {
     int ppb1 = ceil_div(npix, 256);
     if (ppb1 < 1024) ppb1 = 1024;
     stem_wgrad_c1k3_kernel<<<ceil_div(npix, ppb1), 1024, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb1);
@@ -353,10 +368,13 @@ int mpr_stem_wgrad(const float* x, const void* dy, float* dw, int accumulate, in
   if (ppb < 64) ppb = 64;
   grid = ceil_div(npix, ppb);
   const int maxt = ceil_div(g.taps, ntl);
-  if (maxt == 1) stem_wgrad_kernel<1><<<grid, block, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb);
-  else if (maxt == 2) stem_wgrad_kernel<2><<<grid, block, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb);
-  else if (maxt == 3) stem_wgrad_kernel<3><<<grid, block, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb);
-  else stem_wgrad_kernel<4><<<grid, block, 0, st>>>(x, (const bf16_t*)dy, dw, g, ppb);
+  const size_t dense_b = sizeof(float) * (size_t)K * g.taps;
+  const int dense_ok = dense_b <= 48 * 1024;
+  const size_t lds = dense_ok ? dense_b : 0;
+  if (maxt == 1) stem_wgrad_kernel<1><<<grid, block, lds, st>>>(x, (const bf16_t*)dy, dw, g, ppb, dense_ok);
+  else if (maxt == 2) stem_wgrad_kernel<2><<<grid, block, lds, st>>>(x, (const bf16_t*)dy, dw, g, ppb, dense_ok);
+  else if (maxt == 3) stem_wgrad_kernel<3><<<grid, block, lds, st>>>(x, (const bf16_t*)dy, dw, g, ppb, dense_ok);
+  else stem_wgrad_kernel<4><<<grid, block, lds, st>>>(x, (const bf16_t*)dy, dw, g, ppb, dense_ok);
   MPR_LAUNCH_CHECK("stem_wgrad_kernel");
   return MPR_OK;
 }
