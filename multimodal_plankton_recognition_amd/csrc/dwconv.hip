@@ -360,15 +360,18 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const uint4* __restrict__
 // dw[c][r][s] += sum_slab part[slab][tap][c]   (slabs split over gridDim.y, a few-way atomic per element)
 __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nslabs,
                                                               int RS, int C) {
-  const int i = blockIdx.x * 256 + threadIdx.x;       // = tap * C + c
-  if (i >= RS * C) return;
+  // (threads in dw's own order, c * RS + tap: consecutive lanes add to consecutive addresses -- one cache-line operation per 32
+  //  lanes at the memory side instead of one per lane; the partial rows are read with stride C instead)
+  const int o = blockIdx.x * 256 + threadIdx.x;       // = c * RS + tap
+  if (o >= RS * C) return;
+  const int c = o / RS, tap = o - c * RS;
+  const int i = tap * C + c;
   const int per = (nslabs + gridDim.y - 1) / gridDim.y;
   int s0 = blockIdx.y * per, s1 = s0 + per;
   if (s1 > nslabs) s1 = nslabs;
   float a = 0.f;
   for (int sl = s0; sl < s1; ++sl) a += part[(size_t)sl * RS * C + i];
-  const int tap = i / C, c = i - tap * C;
-  atomicAdd(dw + (size_t)c * RS + tap, a);
+  atomicAdd(dw + o, a);
 }
 
 // y = x * gate[b][c]     x, y: [B][L][C] bf16, gate: [B][C] fp32

@@ -171,15 +171,26 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* __restri
       red[bl][lane][JC + j] = a2[j0 + j];
     }
     __syncthreads();
-    if (bl == 0 && cok) {
+    if (bl == 0) {
+      if (cok) {
 #pragma unroll
-      for (int j = 0; j < JC; ++j)
-        if (j0 + j < rd) {
-          const float s1 = (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
-          const float s2 = (red[0][lane][JC + j] + red[1][lane][JC + j]) + (red[2][lane][JC + j] + red[3][lane][JC + j]);
-          atomicAdd(dw1 + (size_t)(j0 + j) * C + c, s1);
-          atomicAdd(dw2 + (size_t)c * rd + j0 + j, s2);
+        for (int j = 0; j < JC; ++j)
+          if (j0 + j < rd) {
+            const float s1 = (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
+            atomicAdd(dw1 + (size_t)(j0 + j) * C + c, s1);
+          }
+      }
+      // dW2[c][j]: lanes take (channel, bottleneck column) pairs in memory order -- 64 / JC channels x JC consecutive columns
+      // per instruction -- instead of one channel per lane at a stride of rd floats (a cache-line operation per lane)
+      constexpr int CPI = 64 / JC;
+      const int jl = lane % JC, cl = lane / JC;
+      for (int cc = 0; cc < 64; cc += CPI) {
+        const int c2 = blockIdx.x * 64 + cc + cl;
+        if (c2 < C && j0 + jl < rd) {
+          const float s2 = (red[0][cc + cl][JC + jl] + red[1][cc + cl][JC + jl]) + (red[2][cc + cl][JC + jl] + red[3][cc + cl][JC + jl]);
+          atomicAdd(dw2 + (size_t)c2 * rd + j0 + jl, s2);
         }
+      }
     }
   }
 }
